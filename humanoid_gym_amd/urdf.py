@@ -1,0 +1,455 @@
+"""URDF -> flat structure-of-arrays robot model.
+
+Host-side replacement for what the reference obtains from
+``p.loadURDF(path, basePosition=..., baseOrientation=..., flags=URDF_USE_SELF_COLLISION
++ URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS)``
+(/root/reference/humanoid_gym/envs/dancer_env.py:58-60) followed by the
+``getNumJoints`` / ``getJointInfo`` sweep that builds ``joint2Index`` and
+``link2Index`` (dancer_env.py:73-79).
+
+Numbering: joints are indexed depth-first from the root link, visiting each
+link's child joints in declaration order -- the order PyBullet reports
+[upstream recall, see DESIGN.md "parity unpinned"].  Fixed joints keep their
+index in the name maps but are welded into their carrier body for dynamics.
+
+Body frames: every body gets an internal frame at its centre of mass with axes
+along the principal axes of inertia (a Jacobi sweep over the 3x3 tensor, only
+when the tensor has off-diagonal terms), which is what Bullet's URDF importer
+does before it builds a btMultiBody.
+
+Collision: meshes are reduced to the 8 corners of their link-frame bounding box
+(ground contact) plus up to 3 inscribed spheres along the longest box axis
+(self contact); ``<box>``, ``<sphere>`` and ``<cylinder>`` are handled
+analytically.
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+import xml.etree.ElementTree as ET
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .model import FlatModel, SPHERE_GROUND, SPHERE_SELF
+
+BIG = 1.0e30
+
+
+# ----------------------------------------------------------------------------
+# small rotation helpers (float64)
+# ----------------------------------------------------------------------------
+def rpy_to_mat(rpy: Sequence[float]) -> np.ndarray:
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array([
+        [cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+        [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+        [-sp, cp * sr, cp * cr]])
+
+
+def quat_to_mat(q: Sequence[float]) -> np.ndarray:
+    x, y, z, w = q
+    n = math.sqrt(x * x + y * y + z * z + w * w)
+    x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def mat_to_quat(m: np.ndarray) -> np.ndarray:
+    """Rotation matrix -> xyzw quaternion with w >= 0."""
+    t = m[0, 0] + m[1, 1] + m[2, 2]
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        q = [0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        q = [(m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s]
+    else:
+        s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+        q = [(m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s]
+    q = np.array(q)
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def principal_axes(I: np.ndarray, threshold: float = 1e-6, max_steps: int = 30) -> Tuple[np.ndarray, np.ndarray]:
+    """Cyclic Jacobi diagonalisation of a symmetric 3x3 tensor.
+
+    Returns (moments[3], V) with V's columns the principal axes, I = V diag V^T.
+    Each step annihilates the largest off-diagonal element; the sweep stops
+    once that element is below ``threshold`` times the trace of absolute
+    diagonal terms.  The eigenvalues stay in the slot they converge in (no
+    sorting), so an already diagonal tensor is returned untouched.
+    """
+    A = np.array(I, dtype=np.float64)
+    V = np.eye(3)
+    eps = np.finfo(np.float64).eps
+    step = max_steps
+    while step > 0:
+        p, q, r = 0, 1, 2
+        big = abs(A[0, 1])
+        if abs(A[0, 2]) > big:
+            q, r, big = 2, 1, abs(A[0, 2])
+        if abs(A[1, 2]) > big:
+            p, q, r, big = 1, 2, 0, abs(A[1, 2])
+        t = threshold * (abs(A[0, 0]) + abs(A[1, 1]) + abs(A[2, 2]))
+        if big <= t:
+            if big <= eps * t:
+                break
+            step = 1                      # one last clean-up rotation
+        apq = A[p, q]
+        theta = (A[q, q] - A[p, p]) / (2.0 * apq)
+        th2 = theta * theta
+        if th2 * th2 < 10.0 / eps:
+            tt = 1.0 / (theta + math.copysign(math.sqrt(1.0 + th2), theta if theta != 0 else 1.0))
+            c = 1.0 / math.sqrt(1.0 + tt * tt)
+            s = c * tt
+        else:                             # nearly diagonal already
+            tt = 1.0 / (theta * (2.0 + 0.5 / th2))
+            c = 1.0 - 0.5 * tt * tt
+            s = c * tt
+        A[p, q] = A[q, p] = 0.0
+        A[p, p] -= tt * apq
+        A[q, q] += tt * apq
+        arp, arq = A[r, p], A[r, q]
+        A[r, p] = A[p, r] = c * arp - s * arq
+        A[r, q] = A[q, r] = c * arq + s * arp
+        vp, vq = V[:, p].copy(), V[:, q].copy()
+        V[:, p] = c * vp - s * vq
+        V[:, q] = c * vq + s * vp
+        step -= 1
+    if np.linalg.det(V) < 0:
+        V[:, 2] = -V[:, 2]
+    return np.array([A[0, 0], A[1, 1], A[2, 2]]), V
+
+
+# ----------------------------------------------------------------------------
+# geometry helpers
+# ----------------------------------------------------------------------------
+def stl_aabb(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """Axis-aligned bounds of a binary (or ASCII) STL; None if the file is absent."""
+    if not os.path.isfile(path):
+        return None
+    with open(path, "rb") as f:
+        data = f.read()
+    verts = None
+    if len(data) >= 84:
+        (ntri,) = struct.unpack_from("<I", data, 80)
+        if 84 + 50 * ntri == len(data):
+            rec = np.frombuffer(data, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]),
+                                count=ntri, offset=84)
+            verts = rec["v"].reshape(-1, 3).astype(np.float64)
+    if verts is None:                     # ASCII fallback
+        pts = [ln.split()[1:4] for ln in data.decode("ascii", "ignore").splitlines()
+               if ln.strip().startswith("vertex")]
+        if not pts:
+            return None
+        verts = np.array(pts, dtype=np.float64)
+    verts = verts * np.asarray(scale, dtype=np.float64)
+    return verts.min(0), verts.max(0)
+
+
+def _box_spheres(lo: np.ndarray, hi: np.ndarray, self_spheres: bool):
+    """8 corner points (ground) + inscribed spheres along the longest axis (self)."""
+    out = []
+    for ix in (lo[0], hi[0]):
+        for iy in (lo[1], hi[1]):
+            for iz in (lo[2], hi[2]):
+                out.append((np.array([ix, iy, iz]), 0.0, SPHERE_GROUND))
+    if self_spheres:
+        c = 0.5 * (lo + hi)
+        h = 0.5 * (hi - lo)
+        ax = int(np.argmax(h))
+        others = [k for k in range(3) if k != ax]
+        r = float(min(h[others[0]], h[others[1]]))
+        if r > 1e-4:
+            span = max(h[ax] - r, 0.0)
+            k = int(min(3, max(1, round(h[ax] / r))))
+            for j in range(k):
+                off = 0.0 if k == 1 else -span + 2.0 * span * j / (k - 1)
+                p = c.copy()
+                p[ax] += off
+                out.append((p, r, SPHERE_SELF))
+    return out
+
+
+def _floats(s: Optional[str], n: int, default: float = 0.0) -> List[float]:
+    if s is None:
+        return [default] * n
+    v = [float(x) for x in s.split()]
+    assert len(v) == n, s
+    return v
+
+
+# ----------------------------------------------------------------------------
+# the loader
+# ----------------------------------------------------------------------------
+def load_urdf(path: str,
+              base_position: Sequence[float] = (0, 0, 0),
+              base_orientation: Sequence[float] = (0, 0, 0, 1),
+              self_collision: bool = False,
+              default_max_force: float = 100000.0,
+              default_max_vel: float = BIG,
+              mesh_aabbs: Optional[Dict[str, Tuple[Sequence[float], Sequence[float]]]] = None,
+              q_init: Optional[Dict[str, float]] = None,
+              name: Optional[str] = None) -> FlatModel:
+    """Parse ``path`` and flatten it.
+
+    ``base_position`` / ``base_orientation`` place the root LINK frame, as the
+    ``basePosition`` / ``baseOrientation`` arguments of ``loadURDF`` do
+    (dancer_env.py:59).  ``mesh_aabbs`` supplies link-frame bounds for mesh
+    geometry whose files are not on disk.
+    """
+    root = ET.parse(path).getroot()
+    urdf_dir = os.path.dirname(os.path.abspath(path))
+
+    links: Dict[str, dict] = {}
+    for el in root.findall("link"):
+        ln = el.get("name")
+        inertial = None
+        ie = el.find("inertial")
+        if ie is not None:
+            o = ie.find("origin")
+            xyz = _floats(o.get("xyz") if o is not None else None, 3)
+            rpy = _floats(o.get("rpy") if o is not None else None, 3)
+            mass = float(ie.find("mass").get("value"))
+            t = ie.find("inertia")
+            ixx, ixy, ixz, iyy, iyz, izz = (float(t.get(k)) for k in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz"))
+            inertial = dict(xyz=np.array(xyz), rpy=rpy, mass=mass,
+                            I=np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]))
+        cols = []
+        for ce in el.findall("collision"):
+            o = ce.find("origin")
+            xyz = np.array(_floats(o.get("xyz") if o is not None else None, 3))
+            rpy = _floats(o.get("rpy") if o is not None else None, 3)
+            g = ce.find("geometry")
+            cols.append((xyz, rpy_to_mat(rpy), g))
+        links[ln] = dict(inertial=inertial, collisions=cols)
+
+    joints = []
+    for el in root.findall("joint"):
+        o = el.find("origin")
+        ax = el.find("axis")
+        lim = el.find("limit")
+        dyn = el.find("dynamics")
+        joints.append(dict(
+            name=el.get("name"), type=el.get("type"),
+            parent=el.find("parent").get("link"), child=el.find("child").get("link"),
+            xyz=np.array(_floats(o.get("xyz") if o is not None else None, 3)),
+            rpy=_floats(o.get("rpy") if o is not None else None, 3),
+            axis=np.array(_floats(ax.get("xyz") if ax is not None else "1 0 0", 3)),
+            lower=float(lim.get("lower")) if lim is not None and lim.get("lower") is not None else None,
+            upper=float(lim.get("upper")) if lim is not None and lim.get("upper") is not None else None,
+            effort=float(lim.get("effort")) if lim is not None and lim.get("effort") is not None else None,
+            velocity=float(lim.get("velocity")) if lim is not None and lim.get("velocity") is not None else None,
+            damping=float(dyn.get("damping", 0.0)) if dyn is not None else 0.0))
+
+    children = {j["child"] for j in joints}
+    roots = [ln for ln in links if ln not in children]
+    if len(roots) != 1:
+        raise ValueError(f"expected exactly one root link, found {roots}")
+    base_link = roots[0]
+
+    # depth-first numbering, child joints in declaration order
+    by_parent: Dict[str, List[dict]] = {}
+    for j in joints:
+        by_parent.setdefault(j["parent"], []).append(j)
+    ordered: List[dict] = []
+
+    def visit(ln: str) -> None:
+        for j in by_parent.get(ln, []):
+            ordered.append(j)
+            visit(j["child"])
+    visit(base_link)
+
+    # bodies: carrier link + everything welded to it through fixed joints
+    # link -> (body id, R, t) with p_carrier = R p_link + t ; body id -1 = base
+    link_body: Dict[str, Tuple[int, np.ndarray, np.ndarray]] = {base_link: (-1, np.eye(3), np.zeros(3))}
+    joint_dof: List[int] = []
+    dof_joint: List[int] = []
+    for ji, j in enumerate(ordered):
+        Rj, tj = rpy_to_mat(j["rpy"]), j["xyz"]
+        pb, Rp, tp = link_body[j["parent"]]
+        if j["type"] == "fixed":
+            link_body[j["child"]] = (pb, Rp @ Rj, Rp @ tj + tp)
+            joint_dof.append(-1)
+        elif j["type"] in ("revolute", "continuous"):
+            k = len(dof_joint)
+            dof_joint.append(ji)
+            joint_dof.append(k)
+            link_body[j["child"]] = (k, np.eye(3), np.zeros(3))
+        else:
+            raise ValueError(f"joint {j['name']}: type {j['type']!r} not supported (revolute/continuous/fixed)")
+    n = len(dof_joint)
+
+    # lumped inertial of each body in its carrier link frame
+    def lump(body: int):
+        m_tot, first = 0.0, np.zeros(3)
+        parts = []
+        for ln, (b, R, t) in link_body.items():
+            ine = links[ln]["inertial"]
+            if b != body or ine is None or ine["mass"] <= 0.0:
+                continue
+            Ri = R @ rpy_to_mat(ine["rpy"])
+            c = R @ ine["xyz"] + t
+            parts.append((ine["mass"], c, Ri, ine["I"]))
+            m_tot += ine["mass"]
+            first += ine["mass"] * c
+        if m_tot <= 0.0:
+            raise ValueError(f"body {body} has no mass")
+        com = first / m_tot
+        if len(parts) == 1:
+            m, c, Ri, I = parts[0]
+            offd = abs(I[0, 1]) + abs(I[0, 2]) + abs(I[1, 2])
+            if offd == 0.0:
+                return m_tot, com, np.array([I[0, 0], I[1, 1], I[2, 2]]), Ri
+            mom, V = principal_axes(I)
+            return m_tot, com, mom, Ri @ V
+        Itot = np.zeros((3, 3))
+        for m, c, Ri, I in parts:
+            r = c - com
+            Itot += Ri @ I @ Ri.T + m * (np.dot(r, r) * np.eye(3) - np.outer(r, r))
+        mom, V = principal_axes(Itot)
+        return m_tot, com, mom, V
+
+    body_mass = np.zeros(n + 1)
+    body_com = np.zeros((n + 1, 3))
+    body_mom = np.zeros((n + 1, 3))
+    body_RL = np.zeros((n + 1, 3, 3))       # internal -> carrier link frame
+    for b in range(-1, n):
+        body_mass[b + 1], body_com[b + 1], body_mom[b + 1], body_RL[b + 1] = lump(b)
+
+    parent = np.zeros(n, np.int32)
+    R0 = np.zeros((n, 3, 3))
+    axis = np.zeros((n, 3))
+    dvec = np.zeros((n, 3))
+    evec = np.zeros((n, 3))
+    damping = np.zeros(n)
+    lower = np.zeros(n)
+    upper = np.zeros(n)
+    max_force = np.zeros(n)
+    max_vel = np.zeros(n)
+    for k, ji in enumerate(dof_joint):
+        j = ordered[ji]
+        pb, Rp, tp = link_body[j["parent"]]          # parent link inside its carrier
+        parent[k] = pb
+        Rj = Rp @ rpy_to_mat(j["rpy"])               # child link frame -> parent carrier frame
+        tj = Rp @ j["xyz"] + tp                      # pivot in parent carrier frame
+        RLp, RLc = body_RL[pb + 1], body_RL[k + 1]
+        R0[k] = RLc.T @ Rj.T @ RLp
+        a = j["axis"] / np.linalg.norm(j["axis"])
+        axis[k] = RLc.T @ a
+        dvec[k] = RLp.T @ (tj - body_com[pb + 1])
+        evec[k] = RLc.T @ body_com[k + 1]
+        damping[k] = j["damping"]
+        if j["type"] == "continuous" or j["lower"] is None:
+            lower[k], upper[k] = -math.pi, math.pi   # dancer_env.py:80-81
+        else:
+            lower[k], upper[k] = j["lower"], j["upper"]
+        max_force[k] = j["effort"] if j["effort"] else default_max_force
+        max_vel[k] = j["velocity"] if j["velocity"] else default_max_vel
+
+    frame_pos = np.zeros((n + 1, 3))
+    frame_quat = np.zeros((n + 1, 4))
+    for b in range(n + 1):
+        frame_pos[b] = -body_RL[b].T @ body_com[b]
+        frame_quat[b] = mat_to_quat(body_RL[b].T)
+
+    # collision spheres
+    s_link, s_flag, s_pos, s_rad = [], [], [], []
+    missing_meshes = []
+    for ln, (b, R, t) in link_body.items():
+        for xyz, Rc, g in links[ln]["collisions"]:
+            shapes = []
+            if g is None:
+                continue
+            mesh, box, sph, cyl = g.find("mesh"), g.find("box"), g.find("sphere"), g.find("cylinder")
+            if mesh is not None:
+                bounds = None
+                if mesh_aabbs and ln in mesh_aabbs:
+                    bounds = (np.array(mesh_aabbs[ln][0], float), np.array(mesh_aabbs[ln][1], float))
+                else:
+                    fn = mesh.get("filename").replace("package://", "")
+                    bounds = stl_aabb(os.path.join(urdf_dir, fn), _floats(mesh.get("scale"), 3, 1.0))
+                if bounds is None:
+                    missing_meshes.append(ln)
+                    continue
+                shapes = _box_spheres(bounds[0], bounds[1], True)
+            elif box is not None:
+                h = 0.5 * np.array(_floats(box.get("size"), 3))
+                shapes = _box_spheres(-h, h, True)
+            elif sph is not None:
+                shapes = [(np.zeros(3), float(sph.get("radius")), SPHERE_GROUND | SPHERE_SELF)]
+            elif cyl is not None:
+                r, L = float(cyl.get("radius")), float(cyl.get("length"))
+                half = max(0.5 * L - r, 0.0)
+                zs = [0.0] if half == 0.0 else ([-half, half] if half < 2 * r else [-half, 0.0, half])
+                shapes = [(np.array([0, 0, z]), r, SPHERE_GROUND | SPHERE_SELF) for z in zs]
+            for p, r, fl in shapes:
+                p_car = R @ (Rc @ p + xyz) + t
+                s_link.append(b)
+                s_flag.append(fl)
+                s_pos.append(body_RL[b + 1].T @ (p_car - body_com[b + 1]))
+                s_rad.append(r)
+
+    # self-collision pairs: different bodies, neither an ancestor of the other
+    # (URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, dancer_env.py:60)
+    pair_a, pair_b = [], []
+    if self_collision:
+        anc = [set() for _ in range(n)]
+        for k in range(n):
+            p = parent[k]
+            while p >= 0:
+                anc[k].add(int(p))
+                p = parent[p]
+        for a in range(len(s_link)):
+            if not (s_flag[a] & SPHERE_SELF) or s_link[a] < 0:
+                continue
+            for b2 in range(a + 1, len(s_link)):
+                if not (s_flag[b2] & SPHERE_SELF) or s_link[b2] < 0:
+                    continue
+                la, lb = s_link[a], s_link[b2]
+                if la == lb or la in anc[lb] or lb in anc[la]:
+                    continue
+                pair_a.append(a)
+                pair_b.append(b2)
+
+    Rwl = quat_to_mat(base_orientation)
+    base_pos0 = np.asarray(base_position, float) + Rwl @ body_com[0]
+    base_quat0 = mat_to_quat(Rwl @ body_RL[0])
+
+    qi = np.zeros(n)
+    if q_init:
+        names = [ordered[ji]["name"] for ji in dof_joint]
+        for nm, v in q_init.items():
+            qi[names.index(nm)] = v
+
+    fm = FlatModel(
+        name=name or root.get("name", "robot"), base_link=base_link,
+        joint_names_all=[j["name"] for j in ordered],
+        link_names_all=[j["child"] for j in ordered],
+        joint_types_all=[j["type"] for j in ordered],
+        joint_dof=joint_dof, dof_joint=dof_joint,
+        parent=parent, R0=R0, axis=axis, d=dvec, e=evec,
+        mass=body_mass[1:].copy(), inertia=body_mom[1:].copy(), joint_damping=damping,
+        lower=lower, upper=upper, max_force=max_force, max_vel=max_vel, q_init=qi,
+        base_mass=float(body_mass[0]), base_inertia=body_mom[0].copy(),
+        base_pos0=base_pos0, base_quat0=base_quat0,
+        frame_pos=frame_pos, frame_quat=frame_quat,
+        sphere_link=np.array(s_link, np.int32), sphere_flags=np.array(s_flag, np.int32),
+        sphere_pos=np.array(s_pos, float).reshape(-1, 3), sphere_radius=np.array(s_rad, float),
+        pair_a=np.array(pair_a, np.int32), pair_b=np.array(pair_b, np.int32),
+        act_joint=np.arange(n, dtype=np.int32),
+        meta={"missing_meshes": missing_meshes,
+              "base_position": list(map(float, base_position)),
+              "base_orientation": list(map(float, base_orientation))})
+    fm.check()
+    return fm

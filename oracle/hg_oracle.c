@@ -1,0 +1,733 @@
+/*
+ * hg_oracle.c -- CPU restatement (plain C, FP64, one env at a time) of the
+ * physics step the reference delegates to PyBullet.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in humanoid_gym_amd/ may import, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and there only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED.  The arithmetic of the path lives in `pybullet` (version not
+ * pinned, /root/reference/setup.py:18), which is absent from /root/reference
+ * and from this image; the reference holds no tests, golden vectors or
+ * recorded trajectories.  This file therefore restates the published
+ * algorithm of Bullet's btMultiBodyDynamicsWorld single step as called from
+ *   /root/reference/humanoid_gym/envs/dancer_env.py:19   setJointMotorControlArray(POSITION_CONTROL)
+ *   /root/reference/humanoid_gym/envs/dancer_env.py:20   stepSimulation()
+ *   /root/reference/humanoid_gym/envs/dancer_env.py:24   getJointState
+ *   /root/reference/humanoid_gym/envs/dancer_env.py:27   getLinkState
+ *   /root/reference/humanoid_gym/envs/dancer_env.py:34   getContactPoints
+ *   /root/reference/humanoid_gym/envs/nao_env.py:70,73   setAngles / getAnglesPosition
+ * and is pinned only by physical invariants (tests/test_oracle_physics.py) and
+ * by the integer fixtures derived from the reference's URDF (tests/golden/).
+ *
+ * One physics step (order of btMultiBodyDynamicsWorld::solveConstraints +
+ * integrateTransforms [upstream recall]):
+ *   1. forward kinematics, contact detection on the CURRENT pose
+ *   2. articulated-body algorithm with gravity and Bullet's link damping,
+ *      velocities += dt * unconstrained acceleration
+ *   3. one velocity-level constraint row per motor (btMultiBodyJointMotor:
+ *      target velocity kp*(q*-q)/dt + (1-kd)*qd clamped to +-max_vel, impulse
+ *      bounded by +-max_force*dt), then per contact one normal row and two
+ *      friction rows; each row needs M^-1 J^T (a unit-impulse ABA response)
+ *   4. projected Gauss-Seidel, fixed iteration count, Bullet's row order
+ *      (motor rows sweep backwards on even iterations, forwards on odd ones;
+ *      then normals; then frictions bounded by mu * current normal impulse)
+ *   5. velocities += M^-1 J^T lambda; positions integrated with the new
+ *      velocities (semi-implicit Euler, quaternion by exponential map).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/hg_model.h"
+
+#define NL HG_MAX_LINKS
+#define NDOF_MAX (6 + HG_MAX_LINKS)
+#define NROWS_MAX (HG_MAX_LINKS + 3 * HG_MAX_CONTACTS)
+
+/* ------------------------------------------------------------------ */
+/* small linear algebra                                                */
+/* ------------------------------------------------------------------ */
+static void v3_cross(const double a[3], const double b[3], double o[3]) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static double v3_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void m3_mulv(const double M[9], const double v[3], double o[3]) {
+    double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+    double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+    double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3_tmulv(const double M[9], const double v[3], double o[3]) { /* M^T v */
+    double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
+    double y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
+    double z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static void m3_mul(const double A[9], const double B[9], double O[9]) {
+    double T[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(O, T, sizeof T);
+}
+static void m3_mul_bt(const double A[9], const double B[9], double O[9]) { /* A B^T */
+    double T[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            T[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+    memcpy(O, T, sizeof T);
+}
+static void quat_to_mat(const double q[4], double R[9]) { /* xyzw, body->world */
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
+}
+static void mat_to_quat(const double m[9], double q[4]) {
+    double t = m[0] + m[4] + m[8], s;
+    if (t > 0) { s = sqrt(t + 1.0) * 2; q[3] = 0.25 * s; q[0] = (m[7] - m[5]) / s; q[1] = (m[2] - m[6]) / s; q[2] = (m[3] - m[1]) / s; }
+    else if (m[0] > m[4] && m[0] > m[8]) { s = sqrt(1.0 + m[0] - m[4] - m[8]) * 2; q[3] = (m[7] - m[5]) / s; q[0] = 0.25 * s; q[1] = (m[1] + m[3]) / s; q[2] = (m[2] + m[6]) / s; }
+    else if (m[4] > m[8]) { s = sqrt(1.0 + m[4] - m[0] - m[8]) * 2; q[3] = (m[2] - m[6]) / s; q[0] = (m[1] + m[3]) / s; q[1] = 0.25 * s; q[2] = (m[5] + m[7]) / s; }
+    else { s = sqrt(1.0 + m[8] - m[0] - m[4]) * 2; q[3] = (m[3] - m[1]) / s; q[0] = (m[2] + m[6]) / s; q[1] = (m[5] + m[7]) / s; q[2] = 0.25 * s; }
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+}
+/* rotation about unit axis a by angle th (active, right-handed) */
+static void axis_angle(const double a[3], double th, double R[9]) {
+    double c = cos(th), s = sin(th), t = 1 - c;
+    R[0] = t * a[0] * a[0] + c;        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
+    R[3] = t * a[0] * a[1] + s * a[2]; R[4] = t * a[1] * a[1] + c;        R[5] = t * a[1] * a[2] - s * a[0];
+    R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = t * a[2] * a[2] + c;
+}
+
+/* spatial vectors are [angular(3); linear(3)] in the body's internal frame */
+
+/* ------------------------------------------------------------------ */
+/* per-env scratch                                                     */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    /* kinematics */
+    double E[NL][9];      /* parent frame -> link frame                     */
+    double r[NL][3];      /* parent COM -> link COM, link frame             */
+    double S[NL][6];      /* joint motion subspace, link frame              */
+    double Rw[NL + 1][9]; /* body frame -> world (index 0 = base)           */
+    double xw[NL + 1][3]; /* body COM in world                              */
+    /* ABA cache (kept for the unit-impulse responses) */
+    double U[NL][6];
+    double Dinv[NL];
+    double IAbase_inv[36];
+} scratch_t;
+
+static void motion_xform(const double E[9], const double r[3], const double vp[6], double vc[6]) {
+    /* child <- parent:  w' = E w ; v' = E v + w' x r */
+    double w[3], v[3], c[3];
+    m3_mulv(E, vp, w);
+    m3_mulv(E, vp + 3, v);
+    v3_cross(w, r, c);
+    vc[0] = w[0]; vc[1] = w[1]; vc[2] = w[2];
+    vc[3] = v[0] + c[0]; vc[4] = v[1] + c[1]; vc[5] = v[2] + c[2];
+}
+static void force_xform_to_parent(const double E[9], const double r[3], const double fc[6], double fp[6]) {
+    /* parent <- child:  f = E^T f_c ; n = E^T (n_c + r x f_c) */
+    double c[3], n[3];
+    v3_cross(r, fc + 3, c);
+    n[0] = fc[0] + c[0]; n[1] = fc[1] + c[1]; n[2] = fc[2] + c[2];
+    m3_tmulv(E, n, fp);
+    m3_tmulv(E, fc + 3, fp + 3);
+}
+static void build_X(const double E[9], const double r[3], double X[36]) {
+    /* 6x6 motion transform child <- parent: [[E,0],[-[r]x E, E]] */
+    double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0}, B[9];
+    m3_mul(rx, E, B);
+    memset(X, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            X[6 * i + j] = E[3 * i + j];
+            X[6 * (i + 3) + j + 3] = E[3 * i + j];
+            X[6 * (i + 3) + j] = -B[3 * i + j];
+        }
+}
+
+/* symmetric positive definite 6x6 inverse via Cholesky */
+static int spd6_inverse(const double A[36], double Ainv[36]) {
+    double L[36] = {0};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[6 * i + j];
+            for (int k = 0; k < j; k++) s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) { if (s <= 0) return -1; L[6 * i + i] = sqrt(s); }
+            else L[6 * i + j] = s / L[6 * j + j];
+        }
+    for (int c = 0; c < 6; c++) {
+        double y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) s -= L[6 * i + k] * y[k];
+            y[i] = s / L[6 * i + i];
+        }
+        for (int i = 5; i >= 0; i--) {
+            double s = y[i];
+            for (int k = i + 1; k < 6; k++) s -= L[6 * k + i] * x[k];
+            x[i] = s / L[6 * i + i];
+        }
+        for (int i = 0; i < 6; i++) Ainv[6 * i + c] = x[i];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* forward kinematics                                                  */
+/* ------------------------------------------------------------------ */
+static void kinematics(const hg_model *m, const double *st, scratch_t *w) {
+    const int n = m->n_links;
+    const double *q = st + HG_STATE_BASE;
+    quat_to_mat(st + 3, w->Rw[0]);
+    memcpy(w->xw[0], st, 3 * sizeof(double));
+    for (int i = 0; i < n; i++) {
+        double Rq[9], t[3];
+        axis_angle(m->axis[i], -q[i], Rq);
+        m3_mul(Rq, m->R0[i], w->E[i]);
+        m3_mulv(w->E[i], m->d[i], t);
+        for (int k = 0; k < 3; k++) w->r[i][k] = m->e[i][k] + t[k];
+        memcpy(w->S[i], m->axis[i], 3 * sizeof(double));
+        v3_cross(m->axis[i], m->e[i], w->S[i] + 3);
+        const int p = m->parent[i] + 1;
+        m3_mul_bt(w->Rw[p], w->E[i], w->Rw[i + 1]);          /* Rw_child = Rw_parent E^T */
+        m3_mulv(w->Rw[i + 1], w->r[i], t);
+        for (int k = 0; k < 3; k++) w->xw[i + 1][k] = w->xw[p][k] + t[k];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* articulated-body algorithm: unconstrained accelerations             */
+/* acc = [base angular (world), base linear (world, of the COM), qdd]  */
+/* ------------------------------------------------------------------ */
+static int aba(const hg_model *m, const hg_config *c, const double *st, const double *tau,
+               scratch_t *w, double *acc) {
+    const int n = m->n_links;
+    const double *qd = st + HG_STATE_BASE + n;
+    double v[NL + 1][6], cor[NL][6], pA[NL + 1][6], IA[NL + 1][36], u[NL], a[NL + 1][6];
+
+    m3_tmulv(w->Rw[0], st + 10, v[0]);        /* base angular velocity, base frame */
+    m3_tmulv(w->Rw[0], st + 7, v[0] + 3);     /* base linear velocity, base frame  */
+
+    for (int b = 0; b <= n; b++) {
+        const int i = b - 1;
+        if (b > 0) {
+            double vj[6];
+            motion_xform(w->E[i], w->r[i], v[m->parent[i] + 1], v[b]);
+            for (int k = 0; k < 6; k++) vj[k] = w->S[i][k] * qd[i];
+            /* c = v x vj (spatial motion cross product) */
+            v3_cross(v[b], vj, cor[i]);
+            double t1[3], t2[3];
+            v3_cross(v[b], vj + 3, t1);
+            v3_cross(v[b] + 3, vj, t2);
+            for (int k = 0; k < 3; k++) cor[i][3 + k] = t1[k] + t2[k];
+            for (int k = 0; k < 6; k++) v[b][k] += vj[k];
+        }
+        const double mass = b ? m->mass[i] : m->base_mass;
+        const double *I = b ? m->inertia[i] : m->base_inertia;
+        memset(IA[b], 0, sizeof IA[b]);
+        for (int k = 0; k < 3; k++) { IA[b][7 * k] = I[k]; IA[b][7 * (k + 3)] = mass; }
+        /* bias force: v x* (I v) - gravity + Bullet's velocity damping */
+        double Iw[3] = {I[0] * v[b][0], I[1] * v[b][1], I[2] * v[b][2]}, g[3], t[3];
+        v3_cross(v[b], Iw, pA[b]);
+        v3_cross(v[b], v[b] + 3, t);
+        m3_tmulv(w->Rw[b], c->gravity, g);
+        const double wn = sqrt(v3_dot(v[b], v[b])), vn = sqrt(v3_dot(v[b] + 3, v[b] + 3));
+        for (int k = 0; k < 3; k++) {
+            pA[b][k] += Iw[k] * (c->ang_damping + c->ang_damping * wn);
+            pA[b][3 + k] = mass * t[k] - mass * g[k] + mass * v[b][3 + k] * (c->lin_damping + c->lin_damping * vn);
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        const int b = i + 1, p = m->parent[i] + 1;
+        double D = 0, Ia[36], pa[6], X[36], T[36];
+        for (int r = 0; r < 6; r++) {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += IA[b][6 * r + k] * w->S[i][k];
+            w->U[i][r] = s;
+        }
+        for (int k = 0; k < 6; k++) D += w->S[i][k] * w->U[i][k];
+        w->Dinv[i] = 1.0 / D;
+        u[i] = (tau ? tau[i] : 0.0) - m->joint_damping[i] * qd[i];
+        for (int k = 0; k < 6; k++) u[i] -= w->S[i][k] * pA[b][k];
+        for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 6; k++) Ia[6 * r + k] = IA[b][6 * r + k] - w->U[i][r] * w->U[i][k] * w->Dinv[i];
+        for (int r = 0; r < 6; r++) {
+            double s = pA[b][r] + w->U[i][r] * u[i] * w->Dinv[i];
+            for (int k = 0; k < 6; k++) s += Ia[6 * r + k] * cor[i][k];
+            pa[r] = s;
+        }
+        build_X(w->E[i], w->r[i], X);
+        for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 6; k++) {
+                double s = 0;
+                for (int j = 0; j < 6; j++) s += Ia[6 * r + j] * X[6 * j + k];
+                T[6 * r + k] = s;
+            }
+        for (int r = 0; r < 6; r++)
+            for (int k = 0; k < 6; k++) {
+                double s = 0;
+                for (int j = 0; j < 6; j++) s += X[6 * j + r] * T[6 * j + k];
+                IA[p][6 * r + k] += s;
+            }
+        double fp[6];
+        force_xform_to_parent(w->E[i], w->r[i], pa, fp);
+        for (int k = 0; k < 6; k++) pA[p][k] += fp[k];
+    }
+    if (spd6_inverse(IA[0], w->IAbase_inv)) return -1;
+    for (int r = 0; r < 6; r++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s -= w->IAbase_inv[6 * r + k] * pA[0][k];
+        a[0][r] = s;
+    }
+    for (int i = 0; i < n; i++) {
+        const int b = i + 1;
+        motion_xform(w->E[i], w->r[i], a[m->parent[i] + 1], a[b]);
+        double s = u[i];
+        for (int k = 0; k < 6; k++) { a[b][k] += cor[i][k]; }
+        for (int k = 0; k < 6; k++) s -= w->U[i][k] * a[b][k];
+        acc[6 + i] = s * w->Dinv[i];
+        for (int k = 0; k < 6; k++) a[b][k] += w->S[i][k] * acc[6 + i];
+    }
+    /* base: world frame, classical acceleration of the COM */
+    double t[3], lin[3];
+    v3_cross(v[0], v[0] + 3, t);
+    for (int k = 0; k < 3; k++) lin[k] = a[0][3 + k] + t[k];
+    m3_mulv(w->Rw[0], a[0], acc);
+    m3_mulv(w->Rw[0], lin, acc + 3);
+    return 0;
+}
+
+/* response to a generalized impulse f (same layout as acc): out = M^-1 f */
+static void impulse_response(const hg_model *m, const scratch_t *w, const double *f, double *out) {
+    const int n = m->n_links;
+    double Z[NL + 1][6], Y[NL], a[NL + 1][6];
+    memset(Z, 0, sizeof(double) * 6 * (n + 1));
+    double t[3];
+    m3_tmulv(w->Rw[0], f, t);
+    for (int k = 0; k < 3; k++) Z[0][k] = -t[k];
+    m3_tmulv(w->Rw[0], f + 3, t);
+    for (int k = 0; k < 3; k++) Z[0][3 + k] = -t[k];
+    for (int i = n - 1; i >= 0; i--) {
+        const int b = i + 1, p = m->parent[i] + 1;
+        double y = f[6 + i], zt[6], fp[6];
+        for (int k = 0; k < 6; k++) y -= w->S[i][k] * Z[b][k];
+        Y[i] = y;
+        for (int k = 0; k < 6; k++) zt[k] = Z[b][k] + w->U[i][k] * y * w->Dinv[i];
+        force_xform_to_parent(w->E[i], w->r[i], zt, fp);
+        for (int k = 0; k < 6; k++) Z[p][k] += fp[k];
+    }
+    for (int r = 0; r < 6; r++) {
+        double s = 0;
+        for (int k = 0; k < 6; k++) s -= w->IAbase_inv[6 * r + k] * Z[0][k];
+        a[0][r] = s;
+    }
+    for (int i = 0; i < n; i++) {
+        const int b = i + 1;
+        motion_xform(w->E[i], w->r[i], a[m->parent[i] + 1], a[b]);
+        double s = Y[i];
+        for (int k = 0; k < 6; k++) s -= w->U[i][k] * a[b][k];
+        out[6 + i] = s * w->Dinv[i];
+        for (int k = 0; k < 6; k++) a[b][k] += w->S[i][k] * out[6 + i];
+    }
+    m3_mulv(w->Rw[0], a[0], out);
+    m3_mulv(w->Rw[0], a[0] + 3, out + 3);
+}
+
+/* Jacobian row: velocity of world point pt on body `body` (-1 = base) along dir */
+static void point_jacobian(const hg_model *m, const scratch_t *w, int body, const double pt[3],
+                           const double dir[3], double sign, double *J) {
+    double rel[3], c[3];
+    for (int k = 0; k < 3; k++) rel[k] = pt[k] - w->xw[0][k];
+    v3_cross(rel, dir, c);
+    for (int k = 0; k < 3; k++) { J[k] += sign * c[k]; J[3 + k] += sign * dir[k]; }
+    for (int i = body; i >= 0; i = m->parent[i]) {
+        double aw[3], ew[3], piv[3];
+        m3_mulv(w->Rw[i + 1], m->axis[i], aw);
+        m3_mulv(w->Rw[i + 1], m->e[i], ew);
+        for (int k = 0; k < 3; k++) piv[k] = pt[k] - (w->xw[i + 1][k] - ew[k]);
+        v3_cross(piv, dir, c);
+        J[6 + i] += sign * v3_dot(aw, c);
+    }
+}
+
+/* Bullet's btPlaneSpace1: two unit tangents p, q orthogonal to n */
+static void plane_space(const double n[3], double p[3], double q[3]) {
+    if (fabs(n[2]) > 0.7071067811865475244) {
+        double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a);
+        p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
+        q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+    } else {
+        double a = n[0] * n[0] + n[1] * n[1], k = 1.0 / sqrt(a);
+        p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0;
+        q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* contact detection                                                   */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int body_a, body_b;     /* body_b = -2 for the ground plane */
+    int sphere_a, sphere_b;
+    double pt[3], n[3], dist;
+} contact_t;
+
+static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_t *w, contact_t *out) {
+    int nc = 0;
+    const int maxc = c->max_contacts < HG_MAX_CONTACTS ? c->max_contacts : HG_MAX_CONTACTS;
+    double cw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
+    for (int s = 0; s < m->n_spheres; s++) {
+        const int b = m->sphere_link[s] + 1;
+        double t[3];
+        m3_mulv(w->Rw[b], m->sphere_pos[s], t);
+        for (int k = 0; k < 3; k++) cw[s][k] = w->xw[b][k] + t[k];
+        dist[s] = cw[s][2] - m->sphere_radius[s];
+    }
+    if (c->enable_ground) {
+        for (int s = 0; s < m->n_spheres && nc < maxc; s++) {
+            if (!(m->sphere_flags[s] & 1) || !(dist[s] < c->contact_margin)) continue;
+            /* at most 4 points per body: keep the 4 smallest (dist, index) */
+            int rank = 0;
+            for (int o = 0; o < m->n_spheres; o++) {
+                if (o == s || m->sphere_link[o] != m->sphere_link[s] || !(m->sphere_flags[o] & 1)) continue;
+                if (!(dist[o] < c->contact_margin)) continue;
+                if (dist[o] < dist[s] || (dist[o] == dist[s] && o < s)) rank++;
+            }
+            if (rank >= 4) continue;
+            contact_t *k = &out[nc++];
+            k->body_a = m->sphere_link[s]; k->body_b = -2; k->sphere_a = s; k->sphere_b = -1;
+            k->n[0] = 0; k->n[1] = 0; k->n[2] = 1;
+            k->pt[0] = cw[s][0]; k->pt[1] = cw[s][1]; k->pt[2] = dist[s];
+            k->dist = dist[s];
+        }
+    }
+    if (c->enable_self) {
+        for (int p = 0; p < m->n_pairs && nc < maxc; p++) {
+            const int a = m->pair_a[p], b = m->pair_b[p];
+            double d[3] = {cw[a][0] - cw[b][0], cw[a][1] - cw[b][1], cw[a][2] - cw[b][2]};
+            const double len = sqrt(v3_dot(d, d));
+            const double ds = len - m->sphere_radius[a] - m->sphere_radius[b];
+            if (!(ds < c->contact_margin) || len < 1e-9) continue;
+            contact_t *k = &out[nc++];
+            k->body_a = m->sphere_link[a]; k->body_b = m->sphere_link[b]; k->sphere_a = a; k->sphere_b = b;
+            for (int j = 0; j < 3; j++) {
+                k->n[j] = d[j] / len;
+                k->pt[j] = 0.5 * ((cw[a][j] - m->sphere_radius[a] * k->n[j]) + (cw[b][j] + m->sphere_radius[b] * k->n[j]));
+            }
+            k->dist = ds;
+        }
+    }
+    return nc;
+}
+
+/* ------------------------------------------------------------------ */
+/* one physics step                                                    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    double J[NDOF_MAX], u[NDOF_MAX];
+    double rhs, diag_inv, lo, hi, lambda;
+    int normal_row;     /* for friction rows: index of the normal row, else -1 */
+} row_t;
+
+static void resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int ndof) {
+    double lo = r->lo, hi = r->hi;
+    if (r->normal_row >= 0) {
+        const double tot = rows[r->normal_row].lambda;
+        if (!(tot > 0)) return;
+        lo = -mu * tot; hi = mu * tot;
+    }
+    double jv = 0;
+    for (int k = 0; k < ndof; k++) jv += r->J[k] * dv[k];
+    double dl = r->rhs - jv * r->diag_inv;
+    double sum = r->lambda + dl;
+    if (sum < lo) sum = lo;
+    if (sum > hi) sum = hi;
+    dl = sum - r->lambda;
+    r->lambda = sum;
+    for (int k = 0; k < ndof; k++) dv[k] += r->u[k] * dl;
+}
+
+typedef struct {
+    int n_contacts;
+    uint64_t link_mask;                    /* bit i+1: link i has a contact, bit 0: base */
+    int pair_a[HG_MAX_CONTACTS], pair_b[HG_MAX_CONTACTS];  /* body indices, -2 = ground */
+    double lambda_n[HG_MAX_CONTACTS];
+} step_info_t;
+
+static int physics_step(const hg_model *m, const hg_config *c, double *st, step_info_t *info) {
+    const int n = m->n_links, ndof = 6 + n;
+    const double dt = c->dt;
+    double *q = st + HG_STATE_BASE, *qd = q + n, *tgt = qd + n;
+    static _Thread_local scratch_t W;
+    static _Thread_local row_t rows[NROWS_MAX];
+    contact_t con[HG_MAX_CONTACTS];
+    double acc[NDOF_MAX], vel[NDOF_MAX], dv[NDOF_MAX];
+
+    kinematics(m, st, &W);
+    const int nc = detect_contacts(m, c, &W, con);
+    if (aba(m, c, st, NULL, &W, acc)) return -1;
+
+    for (int k = 0; k < 3; k++) { st[10 + k] += dt * acc[k]; st[7 + k] += dt * acc[3 + k]; }
+    for (int i = 0; i < n; i++) qd[i] += dt * acc[6 + i];
+    for (int k = 0; k < 3; k++) { vel[k] = st[10 + k]; vel[3 + k] = st[7 + k]; }
+    for (int i = 0; i < n; i++) vel[6 + i] = qd[i];
+
+    /* rows: motors, then contact normals, then friction pairs */
+    int nr = 0;
+    for (int i = 0; i < n; i++) {
+        row_t *r = &rows[nr++];
+        memset(r->J, 0, sizeof(double) * ndof);
+        r->J[6 + i] = 1.0;
+        double target = c->kp * (tgt[i] - q[i]) / dt + qd[i] + c->kd * (0.0 - qd[i]);
+        if (target > m->max_vel[i]) target = m->max_vel[i];
+        if (target < -m->max_vel[i]) target = -m->max_vel[i];
+        impulse_response(m, &W, r->J, r->u);
+        r->diag_inv = 1.0 / r->u[6 + i];
+        r->rhs = (target - qd[i]) * r->diag_inv;
+        r->lo = -m->max_force[i] * dt; r->hi = m->max_force[i] * dt;
+        r->lambda = 0; r->normal_row = -1;
+    }
+    const int first_normal = nr;
+    for (int k = 0; k < nc; k++) {
+        row_t *r = &rows[nr++];
+        memset(r->J, 0, sizeof(double) * ndof);
+        point_jacobian(m, &W, con[k].body_a, con[k].pt, con[k].n, 1.0, r->J);
+        if (con[k].body_b >= -1) point_jacobian(m, &W, con[k].body_b, con[k].pt, con[k].n, -1.0, r->J);
+        impulse_response(m, &W, r->J, r->u);
+        double den = 0, rv = 0;
+        for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
+        r->diag_inv = 1.0 / den;
+        double pos_err = 0, vel_err = -rv;
+        if (con[k].dist > 0) vel_err -= con[k].dist / dt;
+        else pos_err = -con[k].dist * c->contact_erp / dt;
+        r->rhs = (pos_err + vel_err) * r->diag_inv;
+        r->lo = 0; r->hi = 1e10; r->lambda = 0; r->normal_row = -1;
+    }
+    const int first_friction = nr;
+    for (int k = 0; k < nc; k++) {
+        double t[2][3];
+        plane_space(con[k].n, t[0], t[1]);
+        for (int d = 0; d < 2; d++) {
+            row_t *r = &rows[nr++];
+            memset(r->J, 0, sizeof(double) * ndof);
+            point_jacobian(m, &W, con[k].body_a, con[k].pt, t[d], 1.0, r->J);
+            if (con[k].body_b >= -1) point_jacobian(m, &W, con[k].body_b, con[k].pt, t[d], -1.0, r->J);
+            impulse_response(m, &W, r->J, r->u);
+            double den = 0, rv = 0;
+            for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
+            r->diag_inv = 1.0 / den;
+            r->rhs = -rv * r->diag_inv;
+            r->lo = 0; r->hi = 0; r->lambda = 0; r->normal_row = first_normal + k;
+        }
+    }
+
+    memset(dv, 0, sizeof(double) * ndof);
+    for (int it = 0; it < c->solver_iters; it++) {
+        for (int j = 0; j < n; j++) {
+            const int idx = (it & 1) ? j : n - 1 - j;
+            resolve_row(&rows[idx], rows, c->friction, dv, ndof);
+        }
+        for (int j = first_normal; j < first_friction; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
+        for (int j = first_friction; j < nr; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
+    }
+
+    for (int k = 0; k < 3; k++) { st[10 + k] += dv[k]; st[7 + k] += dv[3 + k]; }
+    for (int i = 0; i < n; i++) qd[i] += dv[6 + i];
+
+    /* integrate positions with the new velocities */
+    for (int k = 0; k < 3; k++) st[k] += dt * st[7 + k];
+    for (int i = 0; i < n; i++) q[i] += dt * qd[i];
+    {
+        const double *wv = st + 10;
+        double ang = sqrt(v3_dot(wv, wv)), ax[3], cw;
+        if (ang * dt > 0.7853981633974483) ang = 0.7853981633974483 / dt;  /* Bullet's ANGULAR_MOTION_THRESHOLD */
+        if (ang < 0.001) {
+            const double f = 0.5 * dt - dt * dt * dt * 0.020833333333 * ang * ang;
+            for (int k = 0; k < 3; k++) ax[k] = wv[k] * f;
+        } else {
+            const double f = sin(0.5 * ang * dt) / ang;
+            for (int k = 0; k < 3; k++) ax[k] = wv[k] * f;
+        }
+        cw = cos(0.5 * ang * dt);
+        /* q_new = dq * q  (world-frame angular velocity) */
+        const double x = st[3], y = st[4], z = st[5], s = st[6];
+        double nq[4] = {
+            cw * x + ax[0] * s + ax[1] * z - ax[2] * y,
+            cw * y - ax[0] * z + ax[1] * s + ax[2] * x,
+            cw * z + ax[0] * y - ax[1] * x + ax[2] * s,
+            cw * s - ax[0] * x - ax[1] * y - ax[2] * z};
+        const double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int k = 0; k < 4; k++) st[3 + k] = nq[k] / nn;
+    }
+
+    if (info) {
+        info->n_contacts = nc;
+        info->link_mask = 0;
+        for (int k = 0; k < nc; k++) {
+            info->pair_a[k] = con[k].body_a; info->pair_b[k] = con[k].body_b;
+            info->lambda_n[k] = rows[first_normal + k].lambda;
+            info->link_mask |= 1ull << (con[k].body_a + 1);
+            if (con[k].body_b >= -1) info->link_mask |= 1ull << (con[k].body_b + 1);
+        }
+    }
+    return 0;
+}
+
+/* ================================================================== */
+/* exported API                                                        */
+/* ================================================================== */
+void hgo_reset(const hg_model *m, double *state, int n_envs) {
+    const int n = m->n_links, S = HG_STATE_SIZE(n);
+    for (int e = 0; e < n_envs; e++) {
+        double *st = state + (size_t)e * S;
+        memset(st, 0, sizeof(double) * S);
+        memcpy(st, m->base_pos0, 3 * sizeof(double));
+        memcpy(st + 3, m->base_quat0, 4 * sizeof(double));
+        for (int i = 0; i < n; i++) { st[HG_STATE_BASE + i] = m->q_init[i]; st[HG_STATE_BASE + 2 * n + i] = m->q_init[i]; }
+    }
+}
+
+/*
+ * One env step for n_envs envs: write targets, n_substeps physics steps, read
+ * back (dancer_env.py:19-53 / nao_env.py:70-73).
+ *   actions   [n_envs][n_sel]   target angles (rad)
+ *   joint_sel [n_sel] dof index of each action column; NULL = model act_joint
+ *   obs_q / obs_qd [n_envs][m->n_act]  (nullable)
+ *   base_xyyaw [n_envs][3] base LINK frame x, y, yaw (nullable)
+ *   collision [n_envs] any non-base link in contact (dancer_env.py:32-35)
+ *   link_mask [n_envs] bit b: body b-1 touched something in the LAST substep
+ *   pairs [n_envs][HG_MAX_CONTACTS][2], n_contacts [n_envs]  (nullable)
+ */
+int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
+             const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
+             double *obs_q, double *obs_qd, double *base_xyyaw,
+             uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts) {
+    const int n = m->n_links, S = HG_STATE_SIZE(n);
+    if (joint_sel == NULL) { joint_sel = m->act_joint; n_sel = m->n_act; }
+    for (int k = 0; k < n_sel; k++)
+        if (joint_sel[k] < 0 || joint_sel[k] >= n) return -2;
+    int err = 0;
+#pragma omp parallel for schedule(static) reduction(|:err)
+    for (int e = 0; e < n_envs; e++) {
+        double *st = state + (size_t)e * S;
+        double *q = st + HG_STATE_BASE, *qd = q + n, *tgt = qd + n;
+        step_info_t info;
+        memset(&info, 0, sizeof info);
+        if (actions)
+            for (int k = 0; k < n_sel; k++) {
+                const int j = joint_sel[k];
+                double a = actions[(size_t)e * n_sel + k];
+                if (c->clamp_targets) { if (a < m->lower[j]) a = m->lower[j]; if (a > m->upper[j]) a = m->upper[j]; }
+                tgt[j] = a;
+            }
+        for (int s = 0; s < n_substeps; s++)
+            if (physics_step(m, c, st, &info)) err |= 1;
+        for (int k = 0; k < m->n_act; k++) {
+            if (obs_q) obs_q[(size_t)e * m->n_act + k] = q[m->act_joint[k]];
+            if (obs_qd) obs_qd[(size_t)e * m->n_act + k] = qd[m->act_joint[k]];
+        }
+        if (base_xyyaw) {
+            double R[9], Rf[9], Rl[9], t[3];
+            quat_to_mat(st + 3, R);
+            quat_to_mat(m->frame_quat[0], Rf);
+            m3_mul(R, Rf, Rl);
+            m3_mulv(R, m->frame_pos[0], t);
+            base_xyyaw[3 * e] = st[0] + t[0];
+            base_xyyaw[3 * e + 1] = st[1] + t[1];
+            base_xyyaw[3 * e + 2] = atan2(Rl[3], Rl[0]);
+        }
+        if (collision) collision[e] = (info.link_mask >> 1) != 0;
+        if (link_mask) link_mask[e] = info.link_mask;
+        if (n_contacts) n_contacts[e] = info.n_contacts;
+        if (pairs)
+            for (int k = 0; k < HG_MAX_CONTACTS; k++) {
+                pairs[((size_t)e * HG_MAX_CONTACTS + k) * 2] = k < info.n_contacts ? info.pair_a[k] : -3;
+                pairs[((size_t)e * HG_MAX_CONTACTS + k) * 2 + 1] = k < info.n_contacts ? info.pair_b[k] : -3;
+            }
+    }
+    return err ? -1 : 0;
+}
+
+/* getLinkState (dancer_env.py:27): per body b = 0..n (0 = base)
+ *   com_pos[3], com_quat[4]: internal (inertial) frame in world
+ *   frame_pos[3], frame_quat[4]: URDF link frame in world                 */
+void hgo_link_states(const hg_model *m, const double *state, int n_envs,
+                     double *com_pos, double *com_quat, double *frame_pos, double *frame_quat) {
+    const int n = m->n_links, S = HG_STATE_SIZE(n);
+    static _Thread_local scratch_t W;
+    for (int e = 0; e < n_envs; e++) {
+        kinematics(m, state + (size_t)e * S, &W);
+        for (int b = 0; b <= n; b++) {
+            const size_t o = (size_t)e * (n + 1) + b;
+            double Rf[9], Rl[9], t[3];
+            memcpy(com_pos + 3 * o, W.xw[b], 3 * sizeof(double));
+            mat_to_quat(W.Rw[b], com_quat + 4 * o);
+            quat_to_mat(m->frame_quat[b], Rf);
+            m3_mul(W.Rw[b], Rf, Rl);
+            mat_to_quat(Rl, frame_quat + 4 * o);
+            m3_mulv(W.Rw[b], m->frame_pos[b], t);
+            for (int k = 0; k < 3; k++) frame_pos[3 * o + k] = W.xw[b][k] + t[k];
+        }
+    }
+}
+
+/* ---- hooks for the physics self-consistency tests ------------------ */
+
+/* unconstrained forward dynamics of one env: acc[6+n] */
+int hgo_forward_dynamics(const hg_model *m, const hg_config *c, const double *state, const double *tau, double *acc) {
+    static _Thread_local scratch_t W;
+    kinematics(m, state, &W);
+    return aba(m, c, state, tau, &W, acc);
+}
+
+/* M^-1 f for one env (f, out: [6+n]) */
+int hgo_apply_minv(const hg_model *m, const hg_config *c, const double *state, const double *f, double *out) {
+    static _Thread_local scratch_t W;
+    double acc[NDOF_MAX];
+    kinematics(m, state, &W);
+    if (aba(m, c, state, NULL, &W, acc)) return -1;
+    impulse_response(m, &W, f, out);
+    return 0;
+}
+
+/* kinetic energy, potential energy, linear momentum[3], angular momentum about origin[3] */
+void hgo_energy_momentum(const hg_model *m, const hg_config *c, const double *state, double *out8) {
+    static _Thread_local scratch_t W;
+    const int n = m->n_links;
+    const double *qd = state + HG_STATE_BASE + n;
+    double v[NL + 1][6];
+    kinematics(m, state, &W);
+    m3_tmulv(W.Rw[0], state + 10, v[0]);
+    m3_tmulv(W.Rw[0], state + 7, v[0] + 3);
+    memset(out8, 0, 8 * sizeof(double));
+    for (int b = 0; b <= n; b++) {
+        const int i = b - 1;
+        if (b > 0) {
+            motion_xform(W.E[i], W.r[i], v[m->parent[i] + 1], v[b]);
+            for (int k = 0; k < 6; k++) v[b][k] += W.S[i][k] * qd[i];
+        }
+        const double mass = b ? m->mass[i] : m->base_mass;
+        const double *I = b ? m->inertia[i] : m->base_inertia;
+        double Iw[3] = {I[0] * v[b][0], I[1] * v[b][1], I[2] * v[b][2]}, Lw[3], pw[3], t[3];
+        out8[0] += 0.5 * (v3_dot(v[b], Iw) + mass * v3_dot(v[b] + 3, v[b] + 3));
+        out8[1] -= mass * v3_dot(c->gravity, W.xw[b]);
+        m3_mulv(W.Rw[b], v[b] + 3, pw);
+        m3_mulv(W.Rw[b], Iw, Lw);
+        for (int k = 0; k < 3; k++) pw[k] *= mass;
+        v3_cross(W.xw[b], pw, t);
+        for (int k = 0; k < 3; k++) { out8[2 + k] += pw[k]; out8[5 + k] += Lw[k] + t[k]; }
+    }
+}
+
+/* world-frame pose of every body, for kinematics checks: Rw[(n+1)*9], xw[(n+1)*3] */
+void hgo_kinematics(const hg_model *m, const double *state, double *Rw, double *xw) {
+    static _Thread_local scratch_t W;
+    kinematics(m, state, &W);
+    memcpy(Rw, W.Rw, sizeof(double) * 9 * (m->n_links + 1));
+    memcpy(xw, W.xw, sizeof(double) * 3 * (m->n_links + 1));
+}

@@ -1,0 +1,153 @@
+"""ctypes binding of the CPU oracle (oracle/libhg_oracle.so).
+
+Test infrastructure: imported only by tests/, ``__graft_entry__.smoke()`` and
+``bench.py``'s cpu_baseline leg.  The product package never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from humanoid_gym_amd.model import (FlatModel, HgConfig, HgModel, SimConfig,  # noqa: E402
+                                    HG_MAX_CONTACTS, HG_STATE_BASE)
+
+_LIB = None
+
+
+def build_oracle() -> str:
+    so = os.path.join(ROOT, "oracle", "libhg_oracle.so")
+    src = os.path.join(ROOT, "oracle", "hg_oracle.c")
+    hdr = os.path.join(ROOT, "include", "hg_model.h")
+    if (not os.path.exists(so)) or (os.path.exists(src) and
+                                    os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build_oracle())
+        dp = C.POINTER(C.c_double)
+        L.hgo_reset.argtypes = [C.POINTER(HgModel), dp, C.c_int]
+        L.hgo_reset.restype = None
+        L.hgo_step.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), C.c_int, dp, dp,
+                               C.POINTER(C.c_int32), C.c_int, C.c_int, dp, dp, dp,
+                               C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.hgo_step.restype = C.c_int
+        L.hgo_link_states.argtypes = [C.POINTER(HgModel), dp, C.c_int, dp, dp, dp, dp]
+        L.hgo_link_states.restype = None
+        L.hgo_forward_dynamics.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp, dp]
+        L.hgo_forward_dynamics.restype = C.c_int
+        L.hgo_apply_minv.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp, dp]
+        L.hgo_apply_minv.restype = C.c_int
+        L.hgo_energy_momentum.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp]
+        L.hgo_energy_momentum.restype = None
+        L.hgo_kinematics.argtypes = [C.POINTER(HgModel), dp, dp, dp]
+        L.hgo_kinematics.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+class OracleSim:
+    """Batched FP64 CPU simulation with the same step semantics as the HIP library."""
+
+    def __init__(self, model: FlatModel, cfg: SimConfig, n_envs: int = 1):
+        self.model, self.cfg, self.n_envs = model, cfg, n_envs
+        self.cm, self.cc = model.to_c(), cfg.to_c()
+        self.n = model.n_links
+        self.S = HG_STATE_BASE + 3 * self.n
+        self.state = np.zeros((n_envs, self.S))
+        self.reset()
+
+    def reset(self):
+        lib().hgo_reset(C.byref(self.cm), _dp(self.state), self.n_envs)
+
+    # convenient views
+    @property
+    def q(self):
+        return self.state[:, HG_STATE_BASE:HG_STATE_BASE + self.n]
+
+    @property
+    def qd(self):
+        return self.state[:, HG_STATE_BASE + self.n:HG_STATE_BASE + 2 * self.n]
+
+    @property
+    def targets(self):
+        return self.state[:, HG_STATE_BASE + 2 * self.n:]
+
+    def step(self, actions=None, joint_sel=None, n_substeps=1):
+        na = self.model.n_act
+        obs_q = np.zeros((self.n_envs, na))
+        obs_qd = np.zeros((self.n_envs, na))
+        xyyaw = np.zeros((self.n_envs, 3))
+        col = np.zeros(self.n_envs, np.uint8)
+        mask = np.zeros(self.n_envs, np.uint64)
+        pairs = np.zeros((self.n_envs, HG_MAX_CONTACTS, 2), np.int32)
+        nc = np.zeros(self.n_envs, np.int32)
+        sel_p, n_sel = None, 0
+        if joint_sel is not None:
+            sel = np.ascontiguousarray(joint_sel, np.int32)
+            sel_p, n_sel = sel.ctypes.data_as(C.POINTER(C.c_int32)), len(sel)
+        act = None
+        if actions is not None:
+            act = np.ascontiguousarray(actions, np.float64).reshape(self.n_envs, -1)
+            assert act.shape[1] == (n_sel if joint_sel is not None else na)
+        rc = lib().hgo_step(C.byref(self.cm), C.byref(self.cc), self.n_envs, _dp(self.state), _dp(act),
+                            sel_p, n_sel, n_substeps, _dp(obs_q), _dp(obs_qd), _dp(xyyaw),
+                            col.ctypes.data_as(C.POINTER(C.c_uint8)),
+                            mask.ctypes.data_as(C.POINTER(C.c_uint64)),
+                            pairs.ctypes.data_as(C.POINTER(C.c_int32)),
+                            nc.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc:
+            raise RuntimeError(f"hgo_step failed: {rc}")
+        return dict(q=obs_q, qd=obs_qd, base_xyyaw=xyyaw, collision=col, link_mask=mask,
+                    pairs=pairs, n_contacts=nc)
+
+    def link_states(self):
+        nb = self.n + 1
+        cp, cq = np.zeros((self.n_envs, nb, 3)), np.zeros((self.n_envs, nb, 4))
+        fp, fq = np.zeros((self.n_envs, nb, 3)), np.zeros((self.n_envs, nb, 4))
+        lib().hgo_link_states(C.byref(self.cm), _dp(self.state), self.n_envs, _dp(cp), _dp(cq), _dp(fp), _dp(fq))
+        return cp, cq, fp, fq
+
+    def forward_dynamics(self, env=0, tau=None):
+        acc = np.zeros(6 + self.n)
+        t = None if tau is None else np.ascontiguousarray(tau, np.float64)
+        st = np.ascontiguousarray(self.state[env])
+        rc = lib().hgo_forward_dynamics(C.byref(self.cm), C.byref(self.cc), _dp(st), _dp(t), _dp(acc))
+        assert rc == 0
+        return acc
+
+    def apply_minv(self, f, env=0):
+        out = np.zeros(6 + self.n)
+        st = np.ascontiguousarray(self.state[env])
+        f = np.ascontiguousarray(f, np.float64)
+        rc = lib().hgo_apply_minv(C.byref(self.cm), C.byref(self.cc), _dp(st), _dp(f), _dp(out))
+        assert rc == 0
+        return out
+
+    def energy_momentum(self, env=0):
+        out = np.zeros(8)
+        st = np.ascontiguousarray(self.state[env])
+        lib().hgo_energy_momentum(C.byref(self.cm), C.byref(self.cc), _dp(st), _dp(out))
+        return dict(kinetic=out[0], potential=out[1], p=out[2:5].copy(), L=out[5:8].copy())
+
+    def kinematics(self, env=0):
+        Rw, xw = np.zeros((self.n + 1, 3, 3)), np.zeros((self.n + 1, 3))
+        st = np.ascontiguousarray(self.state[env])
+        lib().hgo_kinematics(C.byref(self.cm), _dp(st), _dp(Rw), _dp(xw))
+        return Rw, xw
