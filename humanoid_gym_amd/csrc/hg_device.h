@@ -1,0 +1,97 @@
+// hg_device.h -- device-side data layout of libhg_sim (gfx950 only).
+//
+// One wavefront (64 lanes) simulates one env.  The robot description is a
+// single read-only DevModel in HBM (about 30 KB, L2 resident); per-env state
+// is an env-major float record (include/hg_model.h, HG_STATE_SIZE) so that the
+// 64 lanes of the env's wave read and write it as one contiguous burst.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hg_model.h"
+
+namespace hg {
+
+constexpr int WAVE  = 64;
+constexpr int DMAX  = 8;    // deepest supported link (base children are depth 1)
+constexpr int NSLOT = 2;    // links whose acceleration must outlive their first child chain
+constexpr int LINKC = 32;   // floats per link in DevModel::link
+constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
+constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
+constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
+constexpr int CON   = 12;   // floats per contact record
+
+// DevModel::link[i][...]
+enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTIA = 22,
+       L_DAMP = 25, L_LOWER = 26, L_UPPER = 27, L_MAXIMP = 28, L_MAXVEL = 29, L_QINIT = 30 };
+// DevModel::base[...]
+enum { B_MASS = 0, B_INERTIA = 1, B_POS0 = 4, B_QUAT0 = 7, B_FPOS = 11, B_FQUAT = 14 };
+
+struct DevModel {
+    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children, n_slots, pad0;
+    int8_t  parent[HG_MAX_LINKS];
+    int8_t  level[HG_MAX_LINKS];        // depth, base children = 1
+    int8_t  first_child[HG_MAX_LINKS];
+    int8_t  next_sibling[HG_MAX_LINKS];
+    int8_t  par_mode[HG_MAX_LINKS];     // 0: parent is link i-1, 1: base, 2+s: saved slot s
+    int8_t  save_slot[HG_MAX_LINKS];    // slot to keep this link's acceleration in, or -1
+    int8_t  act_joint[HG_MAX_LINKS];
+    int8_t  base_children[HG_MAX_LINKS];
+    int8_t  path[HG_MAX_LINKS][DMAX];   // path[b][d-1]: ancestor-or-self of b at depth d, or -1
+    unsigned long long anc_mask[HG_MAX_LINKS];  // bit j: j is b or an ancestor of b
+    float   link[HG_MAX_LINKS][LINKC];
+    float   base[32];
+    int16_t sphere_link[HG_MAX_SPHERES];
+    int16_t grp_begin[HG_MAX_SPHERES];  // [begin,end): spheres on the same body (contiguous)
+    int16_t grp_end[HG_MAX_SPHERES];
+    uint8_t sphere_flags[HG_MAX_SPHERES];
+    float   sphere[HG_MAX_SPHERES][4];  // x y z radius, internal frame of the body
+    int16_t pair_a[HG_MAX_PAIRS];
+    int16_t pair_b[HG_MAX_PAIRS];
+    float   frame_pos[HG_MAX_LINKS + 1][4];
+    float   frame_quat[HG_MAX_LINKS + 1][4];
+};
+
+enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8 };
+
+struct StepParams {
+    int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
+    float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp;
+    int8_t  sel[HG_MAX_LINKS];
+};
+
+struct StepOut {
+    float   *obs_q, *obs_qd, *base_xyyaw, *reward;
+    uint8_t *done, *collision;
+    unsigned long long *link_mask;   // internal, always written
+    int32_t *pairs;                  // internal [n_envs][HG_MAX_CONTACTS][2]
+    int32_t *counts;                 // internal [n_envs]
+};
+
+// LDS carve-up (offsets in floats) for a model with n links / ns spheres.
+struct LdsPlan {
+    int cache, jw, base, vel, F, lam, misc, con, Yd, sdist, AB, total;
+};
+__host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3) {
+    LdsPlan p;
+    int o = 0;
+    const int ndof = rup4(6 + n);
+    p.cache = o; o += CACHE * n;
+    p.jw = o;    o += 8 * n;
+    p.base = o;  o += 64;
+    p.vel = o;   o += ndof;
+    p.F = o;     o += ndof;
+    p.lam = o;   o += 64;
+    p.misc = o;  o += 64;
+    p.con = o;   o += CON * HG_MAX_CONTACTS;
+    p.Yd = o;    o += DMAX * WAVE;
+    p.sdist = o; o += rup4(ns);
+    p.AB = o;
+    int a = PUB * (n + 1) + UP * n;
+    int b = (6 + n) * nc3;
+    o += rup4(a > b ? a : b);
+    p.total = o;
+    return p;
+}
+
+}  // namespace hg

@@ -1,0 +1,463 @@
+// hg_sim.hip -- host side of libhg_sim.so: the C-ABI of include/hg_sim.h, the
+// device model builder and the small helper kernels (reset, link states,
+// joint states, episode statistics).  The fused step kernel is in hg_step.hip.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC hg_sim.hip -o libhg_sim.so
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/hg_sim.h"
+#include "hg_device.h"
+#include "hg_math.h"
+#include "hg_step.hip"
+
+namespace hg {
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HG_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? HG_ENOMEM : HG_ENODEVICE,          \
+                        std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// helper kernels
+// ---------------------------------------------------------------------------------------
+__global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__ state,
+                             const uint8_t *__restrict__ mask, int n_envs) {
+    const int env = blockIdx.x;
+    if (env >= n_envs || (mask && !mask[env])) return;
+    const int n = M->n, S = HG_STATE_SIZE(n);
+    float *st = state + (size_t)env * S;
+    for (int k = threadIdx.x; k < S; k += blockDim.x) {
+        float v = 0.f;
+        if (k < 3) v = M->base[B_POS0 + k];
+        else if (k < 7) v = M->base[B_QUAT0 + k - 3];
+        else if (k >= HG_STATE_BASE && k < HG_STATE_BASE + n) v = M->link[k - HG_STATE_BASE][L_QINIT];
+        else if (k >= HG_STATE_BASE + 2 * n) v = M->link[k - HG_STATE_BASE - 2 * n][L_QINIT];
+        st[k] = v;
+    }
+}
+
+__global__ void joint_state_kernel(const float *__restrict__ state, float *__restrict__ q,
+                                   float *__restrict__ qd, int n, int n_envs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_envs * n) return;
+    const int env = (int)(i / n), j = (int)(i % n);
+    const float *st = state + (size_t)env * HG_STATE_SIZE(n);
+    if (q) q[i] = st[HG_STATE_BASE + j];
+    if (qd) qd[i] = st[HG_STATE_BASE + n + j];
+}
+
+// getLinkState for every body: one wave per env, lane i = link i, level sweep through LDS
+__global__ __launch_bounds__(WAVE)
+void link_state_kernel(const DevModel *__restrict__ M, const float *__restrict__ state,
+                       float *__restrict__ com_pos, float *__restrict__ com_quat,
+                       float *__restrict__ frame_pos, float *__restrict__ frame_quat) {
+    __shared__ float pub[(HG_MAX_LINKS + 1) * 12];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    const int n = M->n;
+    const float *st = state + (size_t)env * HG_STATE_SIZE(n);
+    const bool is_link = lane < n;
+    const int li = is_link ? lane : 0;
+    const float *lk = M->link[li];
+    const int par = is_link ? M->parent[li] : -1;
+    const int pidx = par < 0 ? n : par;
+    const int mylev = is_link ? M->level[li] : 0;
+    M3 Rw = quat_to_mat(st[3], st[4], st[5], st[6]);
+    V3 xw = ld3(st);
+    if (lane == 0) { stm(pub + 12 * n, Rw); st3(pub + 12 * n + 9, xw); }
+    __syncthreads();
+    const float q = is_link ? st[HG_STATE_BASE + lane] : 0.f;
+    float sq, cq;
+    sincosf(-q, &sq, &cq);
+    const M3 E = mul(axis_rot(ld3(lk + L_AXIS), sq, cq), ldm(lk + L_R0));
+    const V3 r = ld3(lk + L_E) + mulv(E, ld3(lk + L_D));
+    for (int lev = 1; lev <= M->maxlev; ++lev) {
+        if (is_link && mylev == lev) {
+            Rw = mul_bt(ldm(pub + 12 * pidx), E);
+            xw = ld3(pub + 12 * pidx + 9) + mulv(Rw, r);
+            stm(pub + 12 * lane, Rw); st3(pub + 12 * lane + 9, xw);
+        }
+        __syncthreads();
+    }
+    // body index: 0 = base (written by lane n), i + 1 = link i
+    int body = -1;
+    if (is_link) body = lane + 1;
+    else if (lane == n) { body = 0; Rw = ldm(pub + 12 * n); xw = ld3(pub + 12 * n + 9); }
+    if (body < 0) return;
+    const size_t o = (size_t)env * (n + 1) + body;
+    float qq[4];
+    if (com_pos) st3(com_pos + 3 * o, xw);
+    if (com_quat) { mat_to_quat(Rw, qq); for (int k = 0; k < 4; k++) com_quat[4 * o + k] = qq[k]; }
+    if (frame_pos) st3(frame_pos + 3 * o, xw + mulv(Rw, ld3(M->frame_pos[body])));
+    if (frame_quat) {
+        const float *fq = M->frame_quat[body];
+        mat_to_quat(mul(Rw, quat_to_mat(fq[0], fq[1], fq[2], fq[3])), qq);
+        for (int k = 0; k < 4; k++) frame_quat[4 * o + k] = qq[k];
+    }
+}
+
+__global__ void copy_contacts_kernel(const int32_t *__restrict__ pairs_in, const int32_t *__restrict__ counts_in,
+                                     const unsigned long long *__restrict__ mask_in,
+                                     int32_t *__restrict__ pairs, int32_t *__restrict__ counts,
+                                     unsigned long long *__restrict__ mask, int n_envs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n_envs * HG_MAX_CONTACTS * 2 && pairs) pairs[i] = pairs_in[i];
+    if (i < (size_t)n_envs) {
+        if (counts) counts[i] = counts_in[i];
+        if (mask) mask[i] = mask_in[i];
+    }
+}
+
+__global__ void stats_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
+                             const uint8_t *__restrict__ collision, float *__restrict__ stats, int n_envs) {
+    float r = 0.f, d = 0.f, c = 0.f, e = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_envs; i += gridDim.x * blockDim.x) {
+        e += 1.f;
+        if (reward) r += reward[i];
+        if (done) d += done[i] ? 1.f : 0.f;
+        if (collision) c += collision[i] ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        e += __shfl_xor(e, o); r += __shfl_xor(r, o); d += __shfl_xor(d, o); c += __shfl_xor(c, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, e); atomicAdd(stats + 1, r); atomicAdd(stats + 2, d); atomicAdd(stats + 3, c);
+    }
+}
+
+}  // namespace hg
+
+// ---------------------------------------------------------------------------------------
+// the handle
+// ---------------------------------------------------------------------------------------
+struct hg_sim {
+    int device = 0;
+    int n_envs = 0, n = 0, n_act = 0, state_size = 0;
+    int variant = 0;            // index into the (NMX, MAXC) instantiation table
+    int lds_bytes = 0;
+    hg_config cfg{};
+    int32_t act_joint[HG_MAX_LINKS]{};
+    hg::DevModel *d_model = nullptr;
+    float *d_state = nullptr;
+    unsigned long long *d_link_mask = nullptr;
+    int32_t *d_pairs = nullptr, *d_counts = nullptr;
+};
+
+namespace hg {
+
+struct Variant { int nmx, maxc; };
+static const Variant kVariants[] = {{18, 12}, {28, 12}, {40, 8}, {46, 6}};
+constexpr int kNumVariants = 4;
+
+static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, std::string *why) {
+    const int n = m->n_links;
+    memset(D, 0, sizeof(DevModel));
+    D->n = n; D->n_spheres = m->n_spheres; D->n_pairs = m->n_pairs; D->n_act = m->n_act;
+    int nchild[HG_MAX_LINKS] = {0}, last_child[HG_MAX_LINKS];
+    int nbc = 0, nslots = 0, maxlev = 0;
+    for (int i = 0; i < n; i++) { D->first_child[i] = -1; D->next_sibling[i] = -1; D->save_slot[i] = -1; last_child[i] = -1; }
+    for (int i = 0; i < n; i++) {
+        const int p = m->parent[i];
+        if (p < -1 || p >= i) { *why = "links must be ordered parents-first"; return HG_EINVAL; }
+        D->parent[i] = (int8_t)p;
+        D->level[i] = (int8_t)(p < 0 ? 1 : D->level[p] + 1);
+        if (D->level[i] > DMAX) { *why = "kinematic tree deeper than DMAX"; return HG_EUNSUPPORTED; }
+        if (D->level[i] > maxlev) maxlev = D->level[i];
+        if (p < 0) D->base_children[nbc++] = (int8_t)i;
+        else {
+            if (last_child[p] < 0) D->first_child[p] = (int8_t)i; else D->next_sibling[last_child[p]] = (int8_t)i;
+            last_child[p] = i; nchild[p]++;
+        }
+        D->anc_mask[i] = (1ull << i) | (p >= 0 ? D->anc_mask[p] : 0ull);
+        for (int d = 0; d < DMAX; d++) D->path[i][d] = -1;
+        for (int a = i; a >= 0; a = m->parent[a]) D->path[i][D->level[a] - 1] = (int8_t)a;
+        // how the full-descent walk finds the parent's acceleration
+        if (p < 0) D->par_mode[i] = 1;
+        else if (p == i - 1) D->par_mode[i] = 0;
+        else {
+            if (D->save_slot[p] < 0) {
+                if (nslots >= NSLOT) { *why = "too many branching links"; return HG_EUNSUPPORTED; }
+                D->save_slot[p] = (int8_t)nslots++;
+            }
+            D->par_mode[i] = (int8_t)(2 + D->save_slot[p]);
+        }
+    }
+    D->maxlev = maxlev; D->n_base_children = nbc; D->n_slots = nslots;
+    for (int k = 0; k < m->n_act; k++) {
+        if (m->act_joint[k] < 0 || m->act_joint[k] >= n) { *why = "act_joint out of range"; return HG_EINVAL; }
+        D->act_joint[k] = (int8_t)m->act_joint[k];
+    }
+    for (int i = 0; i < n; i++) {
+        float *lk = D->link[i];
+        for (int k = 0; k < 9; k++) lk[L_R0 + k] = (float)m->R0[i][k];
+        const double *a = m->axis[i], *e = m->e[i];
+        const double s[3] = {a[1] * e[2] - a[2] * e[1], a[2] * e[0] - a[0] * e[2], a[0] * e[1] - a[1] * e[0]};
+        for (int k = 0; k < 3; k++) {
+            lk[L_AXIS + k] = (float)a[k]; lk[L_S + k] = (float)s[k];
+            lk[L_D + k] = (float)m->d[i][k]; lk[L_E + k] = (float)e[k];
+            lk[L_INERTIA + k] = (float)m->inertia[i][k];
+        }
+        lk[L_MASS] = (float)m->mass[i];
+        lk[L_DAMP] = (float)m->joint_damping[i];
+        lk[L_LOWER] = (float)m->lower[i]; lk[L_UPPER] = (float)m->upper[i];
+        lk[L_MAXIMP] = (float)fmin(m->max_force[i] * c->dt, 1e30);
+        lk[L_MAXVEL] = (float)fmin(m->max_vel[i], 1e30);
+        lk[L_QINIT] = (float)m->q_init[i];
+    }
+    D->base[B_MASS] = (float)m->base_mass;
+    for (int k = 0; k < 3; k++) {
+        D->base[B_INERTIA + k] = (float)m->base_inertia[k];
+        D->base[B_POS0 + k] = (float)m->base_pos0[k];
+        D->base[B_FPOS + k] = (float)m->frame_pos[0][k];
+    }
+    for (int k = 0; k < 4; k++) { D->base[B_QUAT0 + k] = (float)m->base_quat0[k]; D->base[B_FQUAT + k] = (float)m->frame_quat[0][k]; }
+    for (int b = 0; b <= n; b++) {
+        for (int k = 0; k < 3; k++) D->frame_pos[b][k] = (float)m->frame_pos[b][k];
+        for (int k = 0; k < 4; k++) D->frame_quat[b][k] = (float)m->frame_quat[b][k];
+    }
+    for (int s = 0; s < m->n_spheres; s++) {
+        if (m->sphere_link[s] < -1 || m->sphere_link[s] >= n) { *why = "sphere_link out of range"; return HG_EINVAL; }
+        D->sphere_link[s] = (int16_t)m->sphere_link[s];
+        D->sphere_flags[s] = (uint8_t)m->sphere_flags[s];
+        for (int k = 0; k < 3; k++) D->sphere[s][k] = (float)m->sphere_pos[s][k];
+        D->sphere[s][3] = (float)m->sphere_radius[s];
+    }
+    // same-body groups; the "4 deepest per body" rule ranks inside a group, so the
+    // spheres of a body must be contiguous: verify rather than assume
+    for (int s = 0; s < m->n_spheres;) {
+        int e = s;
+        while (e < m->n_spheres && m->sphere_link[e] == m->sphere_link[s]) e++;
+        for (int o = e; o < m->n_spheres; o++)
+            if (m->sphere_link[o] == m->sphere_link[s]) { *why = "collision spheres of one body must be contiguous"; return HG_EINVAL; }
+        for (int k = s; k < e; k++) { D->grp_begin[k] = (int16_t)s; D->grp_end[k] = (int16_t)e; }
+        s = e;
+    }
+    for (int k = 0; k < m->n_pairs; k++) {
+        if (m->pair_a[k] < 0 || m->pair_a[k] >= m->n_spheres || m->pair_b[k] < 0 || m->pair_b[k] >= m->n_spheres) {
+            *why = "self-collision pair out of range"; return HG_EINVAL;
+        }
+        D->pair_a[k] = (int16_t)m->pair_a[k]; D->pair_b[k] = (int16_t)m->pair_b[k];
+    }
+    return HG_OK;
+}
+
+template <int NMX, int MAXC>
+static hipError_t launch_step(const hg_sim *s, const StepParams &P, const float *actions, const StepOut &O, hipStream_t st) {
+    hipLaunchKernelGGL((hg_step_kernel<NMX, MAXC>), dim3(s->n_envs), dim3(WAVE), s->lds_bytes, st,
+                       s->d_model, P, s->d_state, actions, O);
+    return hipGetLastError();
+}
+
+}  // namespace hg
+
+using namespace hg;
+
+// ---------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char *hg_last_error(void) { return g_err.c_str(); }
+int hg_abi_version(void) { return 1; }
+
+int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
+    if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");
+    *out = nullptr;
+    if (n_envs <= 0) return fail(HG_EINVAL, "hg_create: n_envs must be positive");
+    const int n = model->n_links;
+    if (n <= 0 || n > HG_MAX_LINKS) return fail(HG_EINVAL, "hg_create: n_links out of range");
+    if (model->n_spheres < 0 || model->n_spheres > HG_MAX_SPHERES || model->n_pairs < 0 || model->n_pairs > HG_MAX_PAIRS ||
+        model->n_act < 0 || model->n_act > n)
+        return fail(HG_EINVAL, "hg_create: model sizes out of range");
+    if (config->max_contacts < 0 || config->max_contacts > HG_MAX_CONTACTS || config->solver_iters < 0 || !(config->dt > 0))
+        return fail(HG_EINVAL, "hg_create: bad config (max_contacts, solver_iters or dt)");
+    if (config->enable_self) return fail(HG_EUNSUPPORTED, "hg_create: self-collision rows are not built yet");
+    int variant = -1;
+    for (int v = 0; v < kNumVariants; v++)
+        if (kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts) { variant = v; break; }
+    if (variant < 0) return fail(HG_EUNSUPPORTED, "hg_create: no kernel variant for this (n_links, max_contacts)");
+
+    int ndev = 0;
+    HG_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(HG_ENODEVICE, "hg_create: no such HIP device");
+    HG_HIP(hipSetDevice(device_id));
+
+    DevModel *hm = new (std::nothrow) DevModel;
+    if (!hm) return fail(HG_ENOMEM, "hg_create: host allocation failed");
+    std::string why;
+    int rc = build_dev_model(model, config, hm, &why);
+    if (rc) { delete hm; return fail(rc, "hg_create: " + why); }
+
+    hg_sim *s = new (std::nothrow) hg_sim;
+    if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }
+    s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
+    s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
+    memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc).total;
+
+    hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
+    if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_size);
+    if (e == hipSuccess) e = hipMalloc(&s->d_link_mask, sizeof(unsigned long long) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
+    if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMemcpy(s->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
+    if (e == hipSuccess) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
+    delete hm;
+    if (e != hipSuccess) {
+        const std::string msg = std::string("hg_create: ") + hipGetErrorString(e);
+        hg_destroy(s);
+        return fail(e == hipErrorOutOfMemory ? HG_ENOMEM : HG_ENODEVICE, msg);
+    }
+    rc = hg_reset(s, nullptr, nullptr);
+    if (rc == HG_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(HG_ENODEVICE, "hg_create: reset kernel failed");
+    if (rc) { hg_destroy(s); return rc; }
+    *out = s;
+    return HG_OK;
+}
+
+int hg_destroy(hg_sim *s) {
+    if (!s) return HG_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_model); (void)hipFree(s->d_state); (void)hipFree(s->d_link_mask);
+    (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts);
+    delete s;
+    return HG_OK;
+}
+
+int hg_reset(hg_sim *s, const uint8_t *env_mask_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_reset: null handle");
+    HG_HIP(hipSetDevice(s->device));
+    hipLaunchKernelGGL(reset_kernel, dim3(s->n_envs), dim3(WAVE), 0, (hipStream_t)stream,
+                       s->d_model, s->d_state, env_mask_dev, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n_sel, int n_substeps,
+            float *obs_q_dev, float *obs_qd_dev, float *base_xyyaw_dev,
+            float *reward_dev, uint8_t *done_dev, uint8_t *collision_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_step: null handle");
+    if (n_substeps < 1 || n_substeps > 1024) return fail(HG_EINVAL, "hg_step: n_substeps must be in 1..1024");
+    StepParams P;
+    memset(&P, 0, sizeof P);
+    if (joint_sel == nullptr) { joint_sel = s->act_joint; n_sel = s->n_act; }
+    if (n_sel < 0 || n_sel > s->n) return fail(HG_EINVAL, "hg_step: n_sel out of range");
+    unsigned long long seen = 0;
+    for (int k = 0; k < n_sel; k++) {
+        if (joint_sel[k] < 0 || joint_sel[k] >= s->n) return fail(HG_EINVAL, "hg_step: joint_sel entry out of range");
+        if (seen & (1ull << joint_sel[k])) return fail(HG_EINVAL, "hg_step: joint_sel names a joint twice");
+        seen |= 1ull << joint_sel[k];
+        P.sel[k] = (int8_t)joint_sel[k];
+    }
+    const hg_config &c = s->cfg;
+    P.n_envs = s->n_envs; P.n_substeps = n_substeps; P.iters = c.solver_iters; P.maxc = c.max_contacts;
+    P.n_sel = n_sel;
+    P.flags = (c.enable_ground ? F_GROUND : 0) | (c.clamp_targets ? F_CLAMP : 0) |
+              ((actions_dev && n_sel > 0) ? F_ACTIONS : 0);
+    P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
+    P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];
+    P.kp = (float)c.kp; P.kd = (float)c.kd; P.erp = (float)c.contact_erp; P.mu = (float)c.friction;
+    P.margin = (float)c.contact_margin; P.lin_damp = (float)c.lin_damping; P.ang_damp = (float)c.ang_damping;
+    StepOut O;
+    O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;
+    O.done = done_dev; O.collision = collision_dev;
+    O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts;
+    HG_HIP(hipSetDevice(s->device));
+    hipError_t e;
+    hipStream_t st = (hipStream_t)stream;
+    switch (s->variant) {
+        case 0: e = launch_step<18, 12>(s, P, actions_dev, O, st); break;
+        case 1: e = launch_step<28, 12>(s, P, actions_dev, O, st); break;
+        case 2: e = launch_step<40, 8>(s, P, actions_dev, O, st); break;
+        default: e = launch_step<46, 6>(s, P, actions_dev, O, st); break;
+    }
+    if (e != hipSuccess) return fail(HG_ENODEVICE, std::string("hg_step: launch failed: ") + hipGetErrorString(e));
+    return HG_OK;
+}
+
+int hg_get_joint_states(hg_sim *s, float *q_dev, float *qd_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_get_joint_states: null handle");
+    HG_HIP(hipSetDevice(s->device));
+    const size_t tot = (size_t)s->n_envs * s->n;
+    hipLaunchKernelGGL(joint_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       s->d_state, q_dev, qd_dev, s->n, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_get_link_states(hg_sim *s, float *com_pos_dev, float *com_quat_dev, float *frame_pos_dev,
+                       float *frame_quat_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_get_link_states: null handle");
+    HG_HIP(hipSetDevice(s->device));
+    hipLaunchKernelGGL(link_state_kernel, dim3(s->n_envs), dim3(WAVE), 0, (hipStream_t)stream,
+                       s->d_model, s->d_state, com_pos_dev, com_quat_dev, frame_pos_dev, frame_quat_dev);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_get_contact_pairs(hg_sim *s, int32_t *pairs_dev, int32_t *counts_dev, uint64_t *link_mask_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_get_contact_pairs: null handle");
+    HG_HIP(hipSetDevice(s->device));
+    const size_t tot = (size_t)s->n_envs * HG_MAX_CONTACTS * 2;
+    hipLaunchKernelGGL(copy_contacts_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       s->d_pairs, s->d_counts, s->d_link_mask, pairs_dev, counts_dev,
+                       (unsigned long long *)link_mask_dev, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_get_state(hg_sim *s, float *state_dev, void *stream) {
+    if (!s || !state_dev) return fail(HG_EINVAL, "hg_get_state: null argument");
+    HG_HIP(hipSetDevice(s->device));
+    HG_HIP(hipMemcpyAsync(state_dev, s->d_state, sizeof(float) * (size_t)s->n_envs * s->state_size,
+                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HG_OK;
+}
+
+int hg_set_state(hg_sim *s, const float *state_dev, void *stream) {
+    if (!s || !state_dev) return fail(HG_EINVAL, "hg_set_state: null argument");
+    HG_HIP(hipSetDevice(s->device));
+    HG_HIP(hipMemcpyAsync(s->d_state, state_dev, sizeof(float) * (size_t)s->n_envs * s->state_size,
+                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HG_OK;
+}
+
+int hg_get_layout(const hg_sim *s, int32_t *n_envs, int32_t *n_links, int32_t *n_act, int32_t *state_size,
+                  int32_t *max_contacts) {
+    if (!s) return fail(HG_EINVAL, "hg_get_layout: null handle");
+    if (n_envs) *n_envs = s->n_envs;
+    if (n_links) *n_links = s->n;
+    if (n_act) *n_act = s->n_act;
+    if (state_size) *state_size = s->state_size;
+    if (max_contacts) *max_contacts = s->cfg.max_contacts;
+    return HG_OK;
+}
+
+int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_dev, const uint8_t *collision_dev,
+                        float *stats_dev, void *stream) {
+    if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_accumulate: null argument");
+    HG_HIP(hipSetDevice(s->device));
+    int blocks = (s->n_envs + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       reward_dev, done_dev, collision_dev, stats_dev, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+}  // extern "C"

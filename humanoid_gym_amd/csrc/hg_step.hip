@@ -1,0 +1,679 @@
+// hg_step.hip -- the fused env-step kernel: one 64-lane wavefront per env.
+//
+// Replaces, for every env at once, the PyBullet calls of
+//   /root/reference/humanoid_gym/envs/dancer_env.py:19-35
+//   /root/reference/humanoid_gym/envs/nao_env.py:70-73 (and pepper/romeo)
+// with one launch: targets -> n_substeps x { kinematics, contact detection,
+// articulated-body algorithm, motor + contact rows, projected Gauss-Seidel,
+// integration } -> observations and contact flags.
+//
+// Lane roles change per phase (FP32 VALU throughout, no MFMA: the operands are
+// 3x3 / 6x6 blocks of a tree recursion, not GEMM tiles):
+//   * kinematics and ABA: lane i owns link i; the tree is swept level by level,
+//     parent <-> child data goes through LDS;
+//   * contact detection: lanes stride over the collision spheres;
+//   * constraint rows: lane r owns row r (motor rows first, then contact
+//     normals, then friction pairs).  Each lane computes M^-1 J_r^T with its own
+//     walk over the tree (path to the root, then a full descent reading the
+//     broadcast ABA cache in LDS) and accumulates ITS ROW of the Delassus matrix
+//     A = J M^-1 J^T in registers;
+//   * PGS: the sweep over rows is unrolled; at row i every lane forms its own
+//     candidate impulse, lane i's change is broadcast with v_readlane and every
+//     lane j updates w_j += A[j][i] * d.  This is the impulse-space form of
+//     Bullet's velocity-space sweep (w = J dv), same iterates, no reductions;
+//   * the final M^-1 J^T lambda is one more level-by-level ABA response.
+#include "hg_device.h"
+#include "hg_math.h"
+
+namespace hg {
+
+// binary-search store so that the branch depth is log2(N), all branches wave-uniform
+template <int LO, int HI, int NA>
+HG_FI void store_at(float (&A)[NA], int i, float v) {
+    if constexpr (HI - LO == 1) {
+        A[LO] = v;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (i < MID) store_at<LO, MID, NA>(A, i, v); else store_at<MID, HI, NA>(A, i, v);
+    }
+}
+
+template <int NMX, int MAXC>
+__global__ __launch_bounds__(WAVE, 4)
+void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *__restrict__ state,
+                    const float *__restrict__ actions, const StepOut O)
+{
+    constexpr int NC3 = 3 * MAXC;
+    constexpr int NROWS = NMX + NC3;
+    static_assert(NROWS <= WAVE, "rows must fit one wavefront");
+
+    extern __shared__ __align__(16) float lds[];
+    const int env = blockIdx.x;
+    const int lane_o = threadIdx.x;
+    const int n_o = M->n;
+    const int lane = lane_o, n = n_o;
+    const int ndof = 6 + n;
+    const int ns = M->n_spheres;
+    const int maxlev = M->maxlev;
+    const LdsPlan L = lds_plan(n, ns, NC3);
+    float *const cacheL = lds + L.cache;
+    float *const jwL = lds + L.jw;
+    float *const baseL = lds + L.base;     // [0:9) Rw0  [9:12) xw0  [12:48) IA0^-1
+    float *const velL = lds + L.vel;
+    float *const FL = lds + L.F;
+    float *const lamL = lds + L.lam;
+    float *const miscL = lds + L.misc;
+    float *const conL = lds + L.con;
+    float *const YdL = lds + L.Yd;
+    float *const sdistL = lds + L.sdist;
+    float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
+    float *const upL = lds + L.AB + PUB * (n + 1);        // UP * n
+    float *const JcL = lds + L.AB;                        // ndof * NC3 (after the ABA is done)
+
+    const bool is_link = lane < n;
+    const int S = HG_STATE_SIZE(n);
+    float *const st = state + (size_t)env * S;
+
+    // ---- per-lane link constants --------------------------------------------------
+    const int li = is_link ? lane : 0;
+    const float *lk = M->link[li];
+    const int par = is_link ? M->parent[li] : -1;
+    const int pidx = par < 0 ? n : par;
+    const int mylev = is_link ? M->level[li] : 0;
+    const int nbc = M->n_base_children;
+
+    // ---- load state ------------------------------------------------------------------
+    float q = 0.f, qd = 0.f, tgt = 0.f;
+    if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; tgt = st[HG_STATE_BASE + 2 * n + lane]; }
+    V3 bpos = ld3(st), bvel = ld3(st + 7), bang = ld3(st + 10);
+    float bq[4] = {st[3], st[4], st[5], st[6]};
+
+    // ---- targets (dancer_env.py:19 / nao_env.py:70) --------------------------------------
+    if (P.flags & F_ACTIONS) {
+        if (is_link) miscL[lane] = tgt;
+        __syncthreads();
+        int mysel = 0;
+        #pragma unroll 1
+        for (int k = 0; k < P.n_sel; ++k) if (lane == k) mysel = P.sel[k];
+        if (lane < P.n_sel) miscL[mysel] = actions[(size_t)env * P.n_sel + lane];
+        __syncthreads();
+        if (is_link) {
+            tgt = miscL[lane];
+            if (P.flags & F_CLAMP) tgt = fminf(fmaxf(tgt, lk[L_LOWER]), lk[L_UPPER]);
+        }
+        __syncthreads();
+    }
+
+    int nc = 0;                       // contacts of the current physics step
+    unsigned long long link_mask = 0;
+
+    #pragma unroll 1
+    for (int sub = 0; sub < P.n_substeps; ++sub) {
+        // Re-derive everything lane- and size-dependent from opaque copies: without this hipcc
+        // hoists hundreds of loop-invariant masks/addresses out of the substep loop and spills them.
+        int lane_v = lane_o, n_s = n_o;
+        asm volatile("" : "+v"(lane_v), "+s"(n_s) :: "memory");
+        const int lane = lane_v, n = n_s;
+        const int ndof = 6 + n;
+        const bool is_link = lane < n;
+        const int li = is_link ? lane : 0;
+        const float *lk = M->link[li];
+        const int par = is_link ? M->parent[li] : -1;
+        const int pidx = par < 0 ? n : par;
+        const int mylev = is_link ? M->level[li] : 0;
+        // ============ 1. kinematics, root -> leaves ============================================
+        const V3 ax = ld3(lk + L_AXIS);
+        const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace
+        Sv Sm; Sm.a = ax; Sm.l = sl;
+        M3 E; V3 r;
+        {
+            float sq, cq;
+            sincosf(-q, &sq, &cq);
+            E = mul(axis_rot(ax, sq, cq), ldm(lk + L_R0));
+            r = ld3(lk + L_E) + mulv(E, ld3(lk + L_D));
+        }
+        Sv v0;
+        {
+            const M3 Rw0 = quat_to_mat(bq[0], bq[1], bq[2], bq[3]);
+            v0.a = tmulv(Rw0, bang); v0.l = tmulv(Rw0, bvel);
+            if (lane == 0) {
+                float *pb = pubL + PUB * n;
+                stm(pb, Rw0); st3(pb + 9, bpos); stsv(pb + 12, v0);
+                stm(baseL, Rw0); st3(baseL + 9, bpos);
+            }
+        }
+        __syncthreads();
+        Sv v = v0;
+        V3 gl = v3(0, 0, 0);                   // gravity in the link frame
+        #pragma unroll 1
+        for (int lev = 1; lev <= maxlev; ++lev) {
+            if (is_link && mylev == lev) {
+                const float *pp = pubL + PUB * pidx;
+                const M3 Rw = mul_bt(ldm(pp), E);
+                const V3 xw = ld3(pp + 9) + mulv(Rw, r);
+                v = sfma(Sm, qd, xmotion(E, r, ldsv(pp + 12)));
+                float *po = pubL + PUB * lane;
+                stm(po, Rw); st3(po + 9, xw); stsv(po + 12, v);
+                gl = tmulv(Rw, v3(P.gx, P.gy, P.gz));
+                // world-frame joint axis and pivot for the contact Jacobians
+                float *pj = jwL + 8 * lane;
+                st3(pj, mulv(Rw, ax));
+                st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
+            }
+            __syncthreads();
+        }
+
+        // ============ 2. contact detection on the current pose =================================
+        nc = 0;
+        link_mask = 0;
+        if (P.flags & F_GROUND) {
+            #pragma unroll 1
+            for (int s = lane; s < ns; s += WAVE) {
+                const int b = M->sphere_link[s];
+                const float *pp = pubL + PUB * (b < 0 ? n : b);
+                const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
+                const float cz = pp[11] + fmaf(pp[6], sp.x, fmaf(pp[7], sp.y, pp[8] * sp.z));
+                sdistL[s] = (M->sphere_flags[s] & 1) ? cz - sp.w : 1e30f;
+            }
+            __syncthreads();
+            int count = 0;
+            #pragma unroll 1
+            for (int s0 = 0; s0 < ns; s0 += WAVE) {
+                const int s = s0 + lane;
+                bool act = false;
+                float d = 1e30f;
+                if (s < ns) {
+                    d = sdistL[s];
+                    if (d < P.margin) {
+                        int rank = 0;
+                        const int ge = M->grp_end[s];
+                        #pragma unroll 1
+                        for (int o = M->grp_begin[s]; o < ge; ++o) {
+                            const float od = sdistL[o];
+                            rank += (o != s && od < P.margin && (od < d || (od == d && o < s))) ? 1 : 0;
+                        }
+                        act = rank < 4;
+                    }
+                }
+                const unsigned long long bal = __ballot(act);
+                const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
+                if (act && slot < P.maxc) {
+                    const int b = M->sphere_link[s];
+                    const float *pp = pubL + PUB * (b < 0 ? n : b);
+                    const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
+                    const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
+                    float *co = conL + CON * slot;
+                    co[0] = __int_as_float(b); co[1] = __int_as_float(-2);
+                    co[2] = c.x; co[3] = c.y; co[4] = d;
+                    co[5] = 0.f; co[6] = 0.f; co[7] = 1.f; co[8] = d;
+                }
+                count += __popcll(bal);
+            }
+            nc = count < P.maxc ? count : P.maxc;
+        }
+
+        // ============ 3. articulated-body algorithm ============================================
+        // bias forces and rigid-body inertias, every link in parallel
+        Sv cor, pA;
+        AI IA;
+        float u = 0.f, Dinv = 0.f;
+        Sv U;
+        {
+            Sv vj; vj.a = ax * qd; vj.l = sl * qd;
+            // v already contains vj; v x vj == (v - vj) x vj + 0, use v directly (vj x vj = 0 for the
+            // angular part; the linear part keeps both terms)
+            cor.a = cross(v.a, vj.a);
+            cor.l = cross(v.a, vj.l) + cross(v.l, vj.a);
+            const float mass = lk[L_MASS];
+            const V3 inertia = ld3(lk + L_INERTIA);
+            const V3 Iw = v3(inertia.x * v.a.x, inertia.y * v.a.y, inertia.z * v.a.z);
+            const V3 g = gl;
+            const float wn = sqrtf(dot(v.a, v.a)), vn = sqrtf(dot(v.l, v.l));
+            pA.a = cross(v.a, Iw) + Iw * (P.ang_damp + P.ang_damp * wn);
+            pA.l = (cross(v.a, v.l) - g + v.l * (P.lin_damp + P.lin_damp * vn)) * mass;
+            IA.A.xx = inertia.x; IA.A.yy = inertia.y; IA.A.zz = inertia.z; IA.A.xy = IA.A.xz = IA.A.yz = 0.f;
+            IA.C.xx = IA.C.yy = IA.C.zz = mass; IA.C.xy = IA.C.xz = IA.C.yz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) IA.B.m[k] = 0.f;
+        }
+        // leaves -> root
+        #pragma unroll 1
+        for (int lev = maxlev; lev >= 1; --lev) {
+            if (is_link && mylev == lev) {
+                #pragma unroll 1
+                for (int c = M->first_child[lane]; c >= 0; c = M->next_sibling[c]) {
+                    const float *pu = upL + UP * c;
+                    IA.A.xx += pu[0]; IA.A.xy += pu[1]; IA.A.xz += pu[2]; IA.A.yy += pu[3]; IA.A.yz += pu[4]; IA.A.zz += pu[5];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) IA.B.m[k] += pu[6 + k];
+                    IA.C.xx += pu[15]; IA.C.xy += pu[16]; IA.C.xz += pu[17]; IA.C.yy += pu[18]; IA.C.yz += pu[19]; IA.C.zz += pu[20];
+                    pA = pA + ldsv(pu + 21);
+                }
+                U = ai_mul(IA, Sm);
+                const float D = sdot(Sm, U);
+                Dinv = 1.0f / D;
+                u = -lk[L_DAMP] * qd - sdot(Sm, pA);
+                AI Ia = IA;
+                sym_rank1_sub(Ia.A, U.a, Dinv);
+                sym_rank1_sub(Ia.C, U.l, Dinv);
+                {
+                    const float ua[3] = {U.a.x * Dinv, U.a.y * Dinv, U.a.z * Dinv};
+                    const float ul[3] = {U.l.x, U.l.y, U.l.z};
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) Ia.B.m[3 * i + j] = fmaf(-ua[i], ul[j], Ia.B.m[3 * i + j]);
+                }
+                Sv pa = sfma(U, u * Dinv, pA + ai_mul(Ia, cor));
+                const AI Ip = ai_to_parent(Ia, E, r);
+                const Sv pp = xforce_up(E, r, pa);
+                float *pu = upL + UP * lane;
+                pu[0] = Ip.A.xx; pu[1] = Ip.A.xy; pu[2] = Ip.A.xz; pu[3] = Ip.A.yy; pu[4] = Ip.A.yz; pu[5] = Ip.A.zz;
+#pragma unroll
+                for (int k = 0; k < 9; k++) pu[6 + k] = Ip.B.m[k];
+                pu[15] = Ip.C.xx; pu[16] = Ip.C.xy; pu[17] = Ip.C.xz; pu[18] = Ip.C.yy; pu[19] = Ip.C.yz; pu[20] = Ip.C.zz;
+                stsv(pu + 21, pp);
+                float *pc = cacheL + CACHE * lane;
+                stm(pc, E); st3(pc + 9, r); stsv(pc + 12, U); pc[18] = Dinv; stsv(pc + 20, Sm);
+            }
+            __syncthreads();
+        }
+        // base (every lane computes the same thing; results stay in registers)
+        Sv a0;
+        {
+            float A6[36];
+#pragma unroll
+            for (int k = 0; k < 36; k++) A6[k] = 0.f;
+            const float bmass = M->base[B_MASS];
+            const V3 binertia = ld3(M->base + B_INERTIA);
+            const M3 Rw0 = ldm(baseL);
+            A6[0] = binertia.x; A6[7] = binertia.y; A6[14] = binertia.z; A6[21] = A6[28] = A6[35] = bmass;
+            const V3 Iw = v3(binertia.x * v0.a.x, binertia.y * v0.a.y, binertia.z * v0.a.z);
+            const V3 g = tmulv(Rw0, v3(P.gx, P.gy, P.gz));
+            const float wn = sqrtf(dot(v0.a, v0.a)), vn = sqrtf(dot(v0.l, v0.l));
+            Sv p0;
+            p0.a = cross(v0.a, Iw) + Iw * (P.ang_damp + P.ang_damp * wn);
+            p0.l = (cross(v0.a, v0.l) - g + v0.l * (P.lin_damp + P.lin_damp * vn)) * bmass;
+            #pragma unroll 1
+            for (int k = 0; k < nbc; ++k) {
+                const float *pu = upL + UP * M->base_children[k];
+                A6[0] += pu[0]; A6[1] += pu[1]; A6[2] += pu[2]; A6[7] += pu[3]; A6[8] += pu[4]; A6[14] += pu[5];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) A6[6 * i + 3 + j] += pu[6 + 3 * i + j];
+                A6[21] += pu[15]; A6[22] += pu[16]; A6[23] += pu[17]; A6[28] += pu[18]; A6[29] += pu[19]; A6[35] += pu[20];
+                p0 = p0 + ldsv(pu + 21);
+            }
+            // mirror to the lower triangle
+            A6[6] = A6[1]; A6[12] = A6[2]; A6[13] = A6[8];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) A6[6 * (3 + j) + i] = A6[6 * i + 3 + j];
+            A6[27] = A6[22]; A6[33] = A6[23]; A6[34] = A6[29];
+            float Inv[36];
+            spd6_inverse(A6, Inv);
+            a0 = neg_mul6(Inv, p0);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) baseL[12 + k] = Inv[k];
+                stsv(pubL + PUB * n + 12, a0);
+            }
+        }
+        __syncthreads();
+        // root -> leaves: accelerations
+        float qdd = 0.f;
+        #pragma unroll 1
+        for (int lev = 1; lev <= maxlev; ++lev) {
+            if (is_link && mylev == lev) {
+                Sv a = xmotion(E, r, ldsv(pubL + PUB * pidx + 12)) + cor;
+                qdd = (u - sdot(U, a)) * Dinv;
+                a = sfma(Sm, qdd, a);
+                stsv(pubL + PUB * lane + 12, a);
+            }
+            __syncthreads();
+        }
+        // velocities += dt * unconstrained acceleration
+        qd = fmaf(P.dt, qdd, qd);
+        {
+            const M3 Rw0 = ldm(baseL);
+            bang = bang + mulv(Rw0, a0.a) * P.dt;
+            bvel = bvel + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt;
+        }
+
+        // ============ 4. constraint rows =======================================================
+        // world-frame joint axes and pivots for the contact Jacobians, current velocities
+        if (is_link) velL[6 + lane] = qd;
+        if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
+        __syncthreads();      // region AB (pub/up) is dead from here on: Jc may overwrite it
+
+        const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
+        const int cidx = col < 0 ? -1 : (col < MAXC ? col : (col - MAXC) >> 1);
+        const bool row_contact = cidx >= 0 && cidx < nc;
+        const bool row_motor = is_link;                  // NMX >= n by construction
+        int body = row_motor ? lane : -1;
+        float target_err = 0.f;                          // desired change of J.v
+        V3 Jang = v3(0, 0, 0), Jlin = v3(0, 0, 0);
+        if (nc > 0) {
+            V3 pt = v3(0, 0, 0), dir = v3(0, 0, 0);
+            float dist = 0.f;
+            unsigned long long anc = 0;
+            if (row_contact) {
+                const float *co = conL + CON * cidx;
+                body = __float_as_int(co[0]);
+                pt = ld3(co + 2);
+                const V3 nrm = ld3(co + 5);
+                dist = co[8];
+                V3 t1, t2;
+                plane_space(nrm, t1, t2);
+                dir = col < MAXC ? nrm : (((col - MAXC) & 1) ? t2 : t1);
+                anc = body >= 0 ? M->anc_mask[body] : 0ull;
+                Jang = cross(pt - bpos, dir);
+                Jlin = dir;
+            }
+            float rv = 0.f;
+            if (col >= 0) {
+                #pragma unroll 1
+                for (int i = 0; i < n; ++i) {
+                    const float *pj = jwL + 8 * i;
+                    float j = 0.f;
+                    if ((anc >> i) & 1ull) j = dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                    JcL[(6 + i) * NC3 + col] = j;
+                    rv = fmaf(j, velL[6 + i], rv);
+                }
+                JcL[0 * NC3 + col] = Jang.x; JcL[1 * NC3 + col] = Jang.y; JcL[2 * NC3 + col] = Jang.z;
+                JcL[3 * NC3 + col] = Jlin.x; JcL[4 * NC3 + col] = Jlin.y; JcL[5 * NC3 + col] = Jlin.z;
+                rv += dot(Jang, bang) + dot(Jlin, bvel);
+            }
+            if (row_contact) {
+                if (col < MAXC) {
+                    target_err = -rv;
+                    if (dist > 0.f) target_err -= dist * P.inv_dt;
+                    else target_err -= dist * P.erp * P.inv_dt;
+                } else {
+                    target_err = -rv;
+                }
+            }
+        }
+        if (row_motor) {
+            float tv = fmaf(P.kp * (tgt - q), P.inv_dt, qd) - P.kd * qd;
+            const float maxvel = lk[L_MAXVEL];
+            tv = fminf(fmaxf(tv, -maxvel), maxvel);
+            target_err = tv - qd;
+        }
+        const bool row_active = row_motor || row_contact;
+        const unsigned long long myanc = (row_active && body >= 0) ? M->anc_mask[body] : 0ull;
+        __syncthreads();
+
+        // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
+        float Arow[NROWS];
+#pragma unroll
+        for (int k = 0; k < NROWS; k++) Arow[k] = 0.f;
+        float diag = 0.f;
+        {
+            // (i) walk the own path towards the root, accumulating the zero-acceleration force
+            Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
+#pragma unroll
+            for (int dd = DMAX; dd >= 1; --dd) {
+                float Y = 0.f;
+                if (dd <= maxlev) {      // wave-uniform
+                    const int l = (row_active && body >= 0) ? M->path[body][dd - 1] : -1;
+                    if (l >= 0) {
+                        const float *pc = cacheL + CACHE * l;
+                        const float f = row_motor ? (l == lane ? 1.f : 0.f) : JcL[(6 + l) * NC3 + col];
+                        const Sv Sl = ldsv(pc + 20);
+                        const Sv Ul = ldsv(pc + 12);
+                        Y = f - sdot(Sl, Z);
+                        Z = xforce_up(ldm(pc), ld3(pc + 9), sfma(Ul, Y * pc[18], Z));
+                    }
+                    YdL[(dd - 1) * WAVE + lane] = Y;
+                }
+            }
+            // (ii) base
+            const M3 Rb = ldm(baseL);
+            Z.a = Z.a - tmulv(Rb, Jang);
+            Z.l = Z.l - tmulv(Rb, Jlin);
+            float Inv[36];
+#pragma unroll
+            for (int k = 0; k < 36; k++) Inv[k] = baseL[12 + k];
+            const Sv ab = neg_mul6(Inv, Z);
+            const V3 uba = mulv(Rb, ab.a), ubl = mulv(Rb, ab.l);
+            diag = dot(uba, Jang) + dot(ubl, Jlin);
+            if (nc > 0) {
+                const float ub[6] = {uba.x, uba.y, uba.z, ubl.x, ubl.y, ubl.z};
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+#pragma unroll
+                    for (int c = 0; c < NC3; c++) Arow[NMX + c] = fmaf(ub[k], JcL[k * NC3 + c], Arow[NMX + c]);
+            }
+            // (iii) full descent: joint accelerations of every link for this row's impulse
+            Sv acur = ab, slot[NSLOT];
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) slot[s] = ab;
+            #pragma unroll 1
+            for (int i = 0; i < n; ++i) {
+                const int mode = M->par_mode[i];
+                Sv ap = acur;
+                if (mode == 1) ap = ab;
+                else if (mode >= 2) {
+#pragma unroll
+                    for (int s = 0; s < NSLOT; s++) if (mode == 2 + s) ap = slot[s];
+                }
+                const float *pc = cacheL + CACHE * i;
+                Sv a = xmotion(ldm(pc), ld3(pc + 9), ap);
+                const int d = M->level[i];
+                const float Y = ((myanc >> i) & 1ull) ? YdL[(d - 1) * WAVE + lane] : 0.f;
+                const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
+                a = sfma(ldsv(pc + 20), qa, a);
+                acur = a;
+                const int sv = M->save_slot[i];
+                if (sv >= 0) {
+#pragma unroll
+                    for (int s = 0; s < NSLOT; s++) if (sv == s) slot[s] = a;
+                }
+                store_at<0, NMX, NROWS>(Arow, i, qa);
+                if (i == lane) diag = qa;
+                if (nc > 0) {
+                    const float *jr = JcL + (6 + i) * NC3;
+#pragma unroll
+                    for (int c = 0; c < NC3; c++) Arow[NMX + c] = fmaf(qa, jr[c], Arow[NMX + c]);
+                    if (col >= 0) diag = fmaf(qa, jr[col], diag);
+                }
+            }
+        }
+
+        // ---- 4b. projected Gauss-Seidel on impulses ------------------------------------------
+        // Per lane j: z_j = lam_j + (b_j - w_j) / A_jj, the unclamped candidate impulse of row j
+        // (w = A lam).  Updating row i by d changes z_j by -A_ji d / A_jj for j != i and leaves
+        // z_i unchanged, so the sweep needs one med3, one subtract, one readlane and one fma per
+        // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
+        float lam = 0.f, z, lo = 0.f, hi = 0.f;
+        {
+            const float dinv = (row_active && diag > 1e-20f) ? 1.0f / diag : 0.f;
+            z = target_err * dinv;
+#pragma unroll
+            for (int k = 0; k < NROWS; k++) Arow[k] = (k == lane) ? 0.f : -Arow[k] * dinv;
+            if (row_motor) { hi = lk[L_MAXIMP]; lo = -hi; }
+            else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
+        }
+
+        #pragma unroll 1
+        for (int it = 0; it < P.iters; ++it) {
+            int lane_it = lane;
+            asm volatile("" : "+v"(lane_it));   // keeps the 64 lane==i masks out of SGPRs
+            auto row_update = [&](const int i, const float rlo, const float rhi) {
+                const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
+                const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lam), i));
+                z = fmaf(Arow[i], dl, z);
+                lam = (lane_it == i) ? cand : lam;
+            };
+            if (it & 1) {
+#pragma unroll
+                for (int i = 0; i < NMX; ++i) row_update(i, lo, hi);
+            } else {
+#pragma unroll
+                for (int i = NMX - 1; i >= 0; --i) row_update(i, lo, hi);
+            }
+            if (nc > 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) row_update(NMX + c, lo, hi);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) {
+                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), NMX + c));
+                        if (tot > 0.f) {
+                            const float lim = P.mu * tot;
+                            row_update(NMX + MAXC + 2 * c, -lim, lim);
+                            row_update(NMX + MAXC + 2 * c + 1, -lim, lim);
+                        }
+                    }
+            }
+        }
+
+        // ============ 5. velocities += M^-1 J^T lambda =========================================
+        lamL[lane] = lam;
+        __syncthreads();      // all reads of Jc by other lanes' Arow accumulation are done as well
+        if (lane < ndof) {
+            float f = lane >= 6 ? lamL[lane - 6] : 0.f;
+            if (nc > 0) {
+                const float *jr = JcL + lane * NC3;
+#pragma unroll
+                for (int c = 0; c < NC3; c++) f = fmaf(jr[c], lamL[NMX + c], f);
+            }
+            FL[lane] = f;
+        }
+        __syncthreads();      // Jc is dead: region AB is reused for the 6-float exchanges below
+        {
+            float *const up6 = lds + L.AB;             // 8 * n
+            float *const pub6 = lds + L.AB + 8 * n;    // 8 * (n + 1)
+            const float Fi = is_link ? FL[6 + lane] : 0.f;
+            float Y = 0.f;
+            const float *pcm = cacheL + CACHE * li;
+            const M3 E = ldm(pcm);
+            const V3 r = ld3(pcm + 9);
+            const Sv U = ldsv(pcm + 12);
+            const float Dinv = pcm[18];
+            const Sv Sm = ldsv(pcm + 20);
+            const M3 Rw0 = ldm(baseL);
+            #pragma unroll 1
+            for (int lev = maxlev; lev >= 1; --lev) {
+                if (is_link && mylev == lev) {
+                    Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
+                    #pragma unroll 1
+                    for (int c = M->first_child[lane]; c >= 0; c = M->next_sibling[c]) Z = Z + ldsv(up6 + 8 * c);
+                    Y = Fi - sdot(Sm, Z);
+                    stsv(up6 + 8 * lane, xforce_up(E, r, sfma(U, Y * Dinv, Z)));
+                }
+                __syncthreads();
+            }
+            Sv Z0; Z0.a = v3(0, 0, 0); Z0.l = v3(0, 0, 0);
+            #pragma unroll 1
+            for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * M->base_children[k]);
+            Z0.a = Z0.a - tmulv(Rw0, ld3(FL));
+            Z0.l = Z0.l - tmulv(Rw0, ld3(FL + 3));
+            float Inv[36];
+#pragma unroll
+            for (int k = 0; k < 36; k++) Inv[k] = baseL[12 + k];
+            const Sv ab = neg_mul6(Inv, Z0);
+            if (lane == 0) stsv(pub6 + 8 * n, ab);
+            __syncthreads();
+            float dq = 0.f;
+            #pragma unroll 1
+            for (int lev = 1; lev <= maxlev; ++lev) {
+                if (is_link && mylev == lev) {
+                    Sv a = xmotion(E, r, ldsv(pub6 + 8 * pidx));
+                    dq = (Y - sdot(U, a)) * Dinv;
+                    a = sfma(Sm, dq, a);
+                    stsv(pub6 + 8 * lane, a);
+                }
+                __syncthreads();
+            }
+            qd += dq;
+            bang = bang + mulv(Rw0, ab.a);
+            bvel = bvel + mulv(Rw0, ab.l);
+        }
+
+        // ============ 6. integrate positions ==================================================
+        q = fmaf(P.dt, qd, q);
+        bpos = bpos + bvel * P.dt;
+        {
+            float ang = sqrtf(dot(bang, bang));
+            if (ang * P.dt > 0.78539816f) ang = 0.78539816f * P.inv_dt;
+            float f;
+            if (ang < 0.001f) f = 0.5f * P.dt - P.dt * P.dt * P.dt * 0.020833333333f * ang * ang;
+            else f = sinf(0.5f * ang * P.dt) / ang;
+            const V3 a = bang * f;
+            const float cw = cosf(0.5f * ang * P.dt);
+            const float x = bq[0], y = bq[1], z = bq[2], s = bq[3];
+            float nq[4] = {cw * x + a.x * s + a.y * z - a.z * y,
+                           cw * y - a.x * z + a.y * s + a.z * x,
+                           cw * z + a.x * y - a.y * x + a.z * s,
+                           cw * s - a.x * x - a.y * y - a.z * z};
+            const float inv = rsqrtf(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) bq[k] = nq[k] * inv;
+        }
+        __syncthreads();
+    }  // substeps
+
+    // ---- non-finite guard: reset the env in place and raise done ---------------------------------
+    bool bad = !(isfinite(q) && isfinite(qd));
+    bad = bad || !(isfinite(bpos.x + bpos.y + bpos.z + bvel.x + bvel.y + bvel.z + bang.x + bang.y + bang.z + bq[0] + bq[1] + bq[2] + bq[3]));
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (any_bad) {
+        q = is_link ? lk[L_QINIT] : 0.f; qd = 0.f; tgt = q;
+        bpos = ld3(M->base + B_POS0); bvel = v3(0, 0, 0); bang = v3(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) bq[k] = M->base[B_QUAT0 + k];
+    }
+
+    // ---- store state -----------------------------------------------------------------------
+    if (is_link) { st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = qd; st[HG_STATE_BASE + 2 * n + lane] = tgt; }
+    if (lane == 0) {
+        st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];
+        st3(st + 7, bvel); st3(st + 10, bang);
+    }
+
+    // ---- observations and flags (dancer_env.py:32-35,51-52; pepper_env.py:64-68) -----------------
+    if (is_link) { miscL[lane] = q; velL[lane] = qd; }
+    __syncthreads();
+    const int na = M->n_act;
+    if (lane < na) {
+        const int j = M->act_joint[lane];
+        if (O.obs_q) O.obs_q[(size_t)env * na + lane] = miscL[j];
+        if (O.obs_qd) O.obs_qd[(size_t)env * na + lane] = velL[j];
+    }
+    {
+        int a = -3, b = -3;
+        if (lane < nc) { a = __float_as_int(conL[CON * lane]); b = __float_as_int(conL[CON * lane + 1]); }
+        if (lane < HG_MAX_CONTACTS) {
+            O.pairs[((size_t)env * HG_MAX_CONTACTS + lane) * 2] = a;
+            O.pairs[((size_t)env * HG_MAX_CONTACTS + lane) * 2 + 1] = b;
+        }
+        unsigned long long bits = 0;
+        if (lane < nc) { bits |= 1ull << (a + 1); if (b >= -1) bits |= 1ull << (b + 1); }
+        unsigned int blo = (unsigned int)bits, bhi = (unsigned int)(bits >> 32);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { blo |= __shfl_xor(blo, o); bhi |= __shfl_xor(bhi, o); }
+        link_mask = ((unsigned long long)bhi << 32) | blo;   // valid on lanes 0..15
+    }
+    if (lane == 0) {
+        O.link_mask[env] = link_mask;
+        O.counts[env] = nc;
+        if (O.collision) O.collision[env] = (link_mask >> 1) != 0ull ? 1 : 0;
+        if (O.reward) O.reward[env] = 0.f;
+        if (O.done) O.done[env] = any_bad ? 1 : 0;
+        if (O.base_xyyaw) {
+            const M3 Rw0 = quat_to_mat(bq[0], bq[1], bq[2], bq[3]);
+            const V3 fp = bpos + mulv(Rw0, ld3(M->base + B_FPOS));
+            const M3 Rl = mul(Rw0, quat_to_mat(M->base[B_FQUAT], M->base[B_FQUAT + 1], M->base[B_FQUAT + 2], M->base[B_FQUAT + 3]));
+            O.base_xyyaw[3 * (size_t)env] = fp.x;
+            O.base_xyyaw[3 * (size_t)env + 1] = fp.y;
+            O.base_xyyaw[3 * (size_t)env + 2] = atan2f(Rl.m[3], Rl.m[0]);
+        }
+    }
+}
+
+}  // namespace hg
