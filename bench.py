@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- NAO env-steps/s at 4096 envs per GPU (BASELINE.json `metric`).
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): the NAO
+joint-trajectory replay of /root/reference/examples/h5_control_nao.py with the
+`inference.h5` file (not in the reference tree) replaced by a synthetic
+trajectory of the same layout: l_joint_angle[T,5], r_joint_angle[T,5], action
+row = l ++ [1] ++ r ++ [1] (h5_control_nao.py:22), applied to the 10 arm joints
++ LHand/RHand through NaoEnv.step's `joints=` argument (nao_env.py:48,70).
+Every env replays the same trajectory with a phase offset env_id mod T.
+PD position control + ground contact on, 1 physics substep (1/240 s) per step.
+
+One "step" = one hg_step launch over all envs of this rank (targets -> physics
+-> observations) + the on-device episode-statistics accumulation; actions are
+resident in HBM before the timed region.  N > 1: one process per GPU
+(torchrun), envs sharded with no data-path collective; the only collective is
+the RCCL all-reduce of the 8-float episode-statistics vector every 16 steps on
+a side stream.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_TRAJ = 240
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def synthetic_replay(model, seed=1234):
+    """[T, 12] float32 action rows in the h5_control_nao layout."""
+    from humanoid_gym_amd.workloads import nao_replay_joints, synthetic_h5_trajectory
+    names = nao_replay_joints()
+    l, r = synthetic_h5_trajectory(model, T=T_TRAJ, seed=seed)
+    rows = np.concatenate([l, np.ones((T_TRAJ, 1), np.float32), r, np.ones((T_TRAJ, 1), np.float32)], axis=1)
+    sel = np.array([model.dof_of(n) for n in names], np.int32)
+    return rows.astype(np.float32), sel
+
+
+def algorithmic_bytes_per_env_step(model, n_sel):
+    """actions + obs + reward + flags + state read and written once."""
+    n = model.n_links
+    return 4 * (n_sel + model.n_act) + 4 + 2 + 2 * 4 * (13 + 2 * n)
+
+
+def algorithmic_flops_per_env_step(model, cfg, n_contacts=8, n_substeps=1):
+    """Flops of the algorithm as the oracle states it (Bullet's velocity-space form), see DESIGN.md:
+    ABA ~300/body, one M^-1 J^T response ~150/body per row, per PGS row a dot + an axpy of length 6+n."""
+    nb, ndof = model.n_links + 1, 6 + model.n_links
+    rows = model.n_links + 3 * n_contacts
+    return n_substeps * (300 * nb + rows * 150 * nb + cfg.solver_iters * rows * 4 * ndof)
+
+
+def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
+    """Oracle (oracle/hg_oracle.c, FP64, OpenMP over envs) on this host, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import OracleSim
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    n_envs = 64 * threads
+    sim = OracleSim(model, cfg, n_envs)
+    phase = np.arange(n_envs) % T_TRAJ
+
+    def run(steps, t0):
+        for t in range(steps):
+            sim.step(rows[(t0 + t + phase) % T_TRAJ], joint_sel=sel)
+    run(4, 0)                                   # thread pool + cache warm-up
+    c0 = time.perf_counter(); run(4, 4); per = (time.perf_counter() - c0) / 4
+    steps = int(max(8, min(400, target_seconds / max(per, 1e-6))))
+    c0 = time.perf_counter(); run(steps, 8); dt = time.perf_counter() - c0
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--robot", default="nao")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from humanoid_gym_amd.robots import load_robot
+    from humanoid_gym_amd._capi import HgSim
+    from humanoid_gym_amd.stats import EpisodeStats
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    model, cfg = load_robot(args.robot)
+    n_envs = args.envs_per_gpu
+    if args.robot == "nao":
+        rows, sel = synthetic_replay(model)
+    else:   # other robots: random targets inside the limits, all controlled joints
+        rng = np.random.default_rng(2)
+        sel = np.asarray(model.act_joint, np.int32)
+        rows = rng.uniform(model.lower[sel], model.upper[sel], (T_TRAJ, len(sel))).astype(np.float32)
+    sim = HgSim(model, cfg, n_envs, dev)
+    # actions for every (time, env) resident in HBM: [T, n_envs, n_sel]
+    first_env = rank * n_envs
+    phase = (torch.arange(n_envs, device=dev) + first_env) % T_TRAJ
+    rows_d = torch.tensor(rows, device=dev)
+    actions = torch.stack([rows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
+    stats = EpisodeStats(sim, reduce_every=16)
+
+    def step(t):
+        sim.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1)
+        stats.update(t)
+
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        step(t)
+    stats.flush()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # the step kernel alone, HIP events on the stream it is launched on
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kreps = max(10, min(args.steps, 100))
+    ev0.record()
+    for t in range(kreps):
+        sim.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1)
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / kreps
+    _, counts, _ = sim.contact_pairs()
+    mean_contacts = float(counts.float().mean().item())
+    finite = bool(torch.isfinite(sim.get_state()).all().item())
+
+    if rank == 0:
+        total_envs = n_envs * world
+        value = total_envs * args.steps / elapsed
+        bytes_step = algorithmic_bytes_per_env_step(model, len(sel))
+        flops_step = algorithmic_flops_per_env_step(model, cfg, n_contacts=int(round(mean_contacts)))
+        ach_gbs = n_envs * bytes_step / (kernel_ms * 1e-3) / 1e9
+        ach_tf = n_envs * flops_step / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "NAO env-steps/sec (4096 envs/GPU)" if args.robot == "nao" else f"{args.robot} env-steps/sec",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NAO h5 joint-trajectory replay (h5_control_nao layout, synthetic sinusoid "
+                                   "trajectory), PD position control + ground contact, 1 substep of 1/240 s"
+                       if args.robot == "nao" else f"{args.robot} random targets",
+                       "robot": model.name + ("_like (stand-in URDF)" if args.robot != "dancer" else ""),
+                       "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters,
+                       "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hg_step_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_env_step": bytes_step,
+                         "note": "metric asks for the HBM fraction; the kernel is FP32-VALU bound, see `valu`"},
+            "valu": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
+                     "algorithmic_flops_per_env_step": flops_step},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -354,8 +354,8 @@ def load_urdf(path: str,
             lower[k], upper[k] = -math.pi, math.pi   # dancer_env.py:80-81
         else:
             lower[k], upper[k] = j["lower"], j["upper"]
-        max_force[k] = j["effort"] if j["effort"] else default_max_force
-        max_vel[k] = j["velocity"] if j["velocity"] else default_max_vel
+        max_force[k] = j["effort"] if j["effort"] is not None else default_max_force
+        max_vel[k] = j["velocity"] if j["velocity"] is not None else default_max_vel
 
     frame_pos = np.zeros((n + 1, 3))
     frame_quat = np.zeros((n + 1, 4))

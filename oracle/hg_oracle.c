@@ -39,6 +39,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__SSE2__)
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+#endif
 
 #include "../include/hg_model.h"
 
@@ -612,8 +616,13 @@ int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
     for (int k = 0; k < n_sel; k++)
         if (joint_sel[k] < 0 || joint_sel[k] >= n) return -2;
     int err = 0;
-#pragma omp parallel for schedule(static) reduction(|:err)
+#pragma omp parallel for schedule(static) reduction(|:err) if (n_envs > 3)
     for (int e = 0; e < n_envs; e++) {
+#if defined(__SSE2__)
+        /* impulses that decay towards zero otherwise run the solver on subnormals (40x slower) */
+        _MM_SET_FLUSH_ZERO_MODE(_MM_FLUSH_ZERO_ON);
+        _MM_SET_DENORMALS_ZERO_MODE(_MM_DENORMALS_ZERO_ON);
+#endif
         double *st = state + (size_t)e * S;
         double *q = st + HG_STATE_BASE, *qd = q + n, *tgt = qd + n;
         step_info_t info;

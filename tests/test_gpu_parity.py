@@ -79,3 +79,85 @@ def test_link_states_match_oracle():
     q, qd = gpu.joint_states()
     assert np.abs(q.cpu().numpy() - cpu.q).max() < 1e-4
     assert np.abs(qd.cpu().numpy() - cpu.qd).max() < 5e-3
+
+
+def _replay(model):
+    from humanoid_gym_amd.workloads import nao_replay_joints, synthetic_h5_trajectory, pack_rows
+    l, r = synthetic_h5_trajectory(model, T=240, seed=1234)
+    rows = pack_rows(l, r)
+    sel = np.array([model.dof_of(n) for n in nao_replay_joints()], np.int32)
+    return rows, sel
+
+
+def test_nao_replay_contact_free_1s():
+    """north_star tolerance: joint positions within 1e-4 rad over a 1 s contact-free replay."""
+    n_envs = 8
+    model, cfg, gpu, cpu, torch = _mk("nao", n_envs, enable_ground=False, gravity=(0.0, 0.0, 0.0))
+    rows, sel = _replay(model)
+    phase = np.arange(n_envs) * 7
+    worst = 0.0
+    for t in range(240):
+        act = rows[(t + phase) % 240]
+        o = cpu.step(act, joint_sel=sel)
+        gq, _, _, _ = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel)
+        worst = max(worst, float(np.abs(gq.cpu().numpy() - o["q"]).max()))
+    assert worst < 1e-4, worst
+
+
+def test_nao_replay_with_ground_contact():
+    """With contact: bounded drift (joint angles, base pose) and identical integer outputs."""
+    n_envs = 8
+    model, cfg, gpu, cpu, torch = _mk("nao", n_envs)
+    rows, sel = _replay(model)
+    phase = np.arange(n_envs) * 11
+    for t in range(240):
+        act = rows[(t + phase) % 240]
+        o = cpu.step(act, joint_sel=sel)
+        gq, _, _, gcol = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel)
+        pairs, counts, mask = gpu.contact_pairs()
+        np.testing.assert_array_equal(counts.cpu().numpy(), o["n_contacts"], err_msg=f"step {t}")
+        np.testing.assert_array_equal(pairs.cpu().numpy(), o["pairs"], err_msg=f"step {t}")
+        np.testing.assert_array_equal(gcol.cpu().numpy(), o["collision"])
+        assert np.abs(gq.cpu().numpy() - o["q"]).max() < 5e-3, t
+    st = gpu.get_state().cpu().numpy()
+    assert np.abs(st[:, :3] - cpu.state[:, :3]).max() < 5e-3          # bounded CoM-frame drift
+    assert np.isfinite(st).all()
+
+
+@pytest.mark.parametrize("name", ["pepper", "romeo"])
+def test_other_robots_random_targets(name):
+    from humanoid_gym_amd.workloads import random_actions
+    n_envs = 4
+    model, cfg, gpu, cpu, torch = _mk(name, n_envs)
+    rng = np.random.default_rng(3)
+    for t in range(60):
+        if t % 20 == 0:
+            act = random_actions(model, rng, n_envs)
+        o = cpu.step(act)
+        gq, _, _, gcol = gpu.step(torch.tensor(act, device="cuda:0"))
+        assert np.abs(gq.cpu().numpy() - o["q"]).max() < 5e-3, t
+    _, counts, _ = gpu.contact_pairs()
+    np.testing.assert_array_equal(counts.cpu().numpy(), o["n_contacts"])
+    xy = gpu.base_xyyaw.cpu().numpy()
+    assert np.abs(xy - o["base_xyyaw"]).max() < 5e-3
+
+
+def test_reset_mask_and_substeps():
+    n_envs = 6
+    model, cfg, gpu, cpu, torch = _mk("dancer", n_envs)
+    act = np.full((n_envs, model.n_act), 0.2)
+    ta = torch.tensor(act, dtype=torch.float32, device="cuda:0")
+    for _ in range(5):
+        cpu.step(act, n_substeps=4)
+        gpu.step(ta, n_substeps=4)
+    assert np.abs(gpu.get_state().cpu().numpy() - cpu.state).max() < 2e-3
+    mask = torch.tensor([1, 0, 1, 0, 0, 1], dtype=torch.uint8, device="cuda:0")
+    before = gpu.get_state().cpu().numpy()
+    gpu.reset(mask)
+    after = gpu.get_state().cpu().numpy()
+    fresh = OracleSim(model, cfg, 1).state[0]
+    for e in range(n_envs):
+        if mask[e]:
+            assert np.abs(after[e] - fresh).max() < 1e-6
+        else:
+            np.testing.assert_array_equal(after[e], before[e])
