@@ -12,7 +12,7 @@
 namespace hg {
 
 constexpr int WAVE  = 64;
-constexpr int DMAX  = 8;    // deepest supported link (base children are depth 1)
+constexpr int DMAX  = 12;   // deepest supported link (base children are depth 1)
 constexpr int NSLOT = 2;    // links whose acceleration must outlive their first child chain
 constexpr int LINKC = 32;   // floats per link in DevModel::link
 constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
@@ -37,6 +37,12 @@ struct DevModel {
     int8_t  act_joint[HG_MAX_LINKS];
     int8_t  base_children[HG_MAX_LINKS];
     int8_t  path[HG_MAX_LINKS][DMAX];   // path[b][d-1]: ancestor-or-self of b at depth d, or -1
+    // packed copies of the tables above, so that the kernel needs one load per lane instead
+    // of one dependent load per tree level / per link:
+    uint32_t linkinfo[HG_MAX_LINKS];    // par_mode | level << 8 | (save_slot + 1) << 16 | (parent + 1) << 24
+    uint32_t kids[HG_MAX_LINKS];        // (first_child + 1) | (next_sibling + 1) << 8
+    uint32_t pathw[HG_MAX_LINKS][4];    // byte d-1 of the 16: path[b][d-1] + 1 (0 = none)
+    uint32_t sphere_meta[HG_MAX_SPHERES]; // (link + 1) | flags << 8 | grp_begin << 16 | grp_end << 24
     unsigned long long anc_mask[HG_MAX_LINKS];  // bit j: j is b or an ancestor of b
     float   link[HG_MAX_LINKS][LINKC];
     float   base[32];
@@ -69,10 +75,10 @@ struct StepOut {
 
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd, sdist, AB, total;
+    int cache, jw, base, vel, F, lam, misc, con, Yd, sdist, tab, AB, total;
 };
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
@@ -84,8 +90,9 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3) {
     p.lam = o;   o += 64;
     p.misc = o;  o += 64;
     p.con = o;   o += CON * HG_MAX_CONTACTS;
-    p.Yd = o;    o += DMAX * WAVE;
+    p.Yd = o;    o += maxlev * WAVE;
     p.sdist = o; o += rup4(ns);
+    p.tab = o;   o += rup4(2 * n);          // int tables: next_sibling[n], base_children[n]
     p.AB = o;
     int a = PUB * (n + 1) + UP * n;
     int b = (6 + n) * nc3;

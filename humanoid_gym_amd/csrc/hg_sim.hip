@@ -196,6 +196,13 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         }
     }
     D->maxlev = maxlev; D->n_base_children = nbc; D->n_slots = nslots;
+    for (int i = 0; i < n; i++) {
+        D->linkinfo[i] = (uint32_t)(uint8_t)D->par_mode[i] | ((uint32_t)(uint8_t)D->level[i] << 8) |
+                         ((uint32_t)(uint8_t)(D->save_slot[i] + 1) << 16) | ((uint32_t)(uint8_t)(D->parent[i] + 1) << 24);
+        D->kids[i] = (uint32_t)(uint8_t)(D->first_child[i] + 1) | ((uint32_t)(uint8_t)(D->next_sibling[i] + 1) << 8);
+        for (int d = 0; d < DMAX; d++)
+            D->pathw[i][d >> 2] |= (uint32_t)(uint8_t)(D->path[i][d] + 1) << (8 * (d & 3));
+    }
     for (int k = 0; k < m->n_act; k++) {
         if (m->act_joint[k] < 0 || m->act_joint[k] >= n) { *why = "act_joint out of range"; return HG_EINVAL; }
         D->act_joint[k] = (int8_t)m->act_joint[k];
@@ -242,7 +249,11 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         while (e < m->n_spheres && m->sphere_link[e] == m->sphere_link[s]) e++;
         for (int o = e; o < m->n_spheres; o++)
             if (m->sphere_link[o] == m->sphere_link[s]) { *why = "collision spheres of one body must be contiguous"; return HG_EINVAL; }
-        for (int k = s; k < e; k++) { D->grp_begin[k] = (int16_t)s; D->grp_end[k] = (int16_t)e; }
+        for (int k = s; k < e; k++) {
+            D->grp_begin[k] = (int16_t)s; D->grp_end[k] = (int16_t)e;
+            D->sphere_meta[k] = (uint32_t)(uint8_t)(m->sphere_link[k] + 1) | ((uint32_t)(m->sphere_flags[k] & 0xff) << 8) |
+                                ((uint32_t)s << 16) | ((uint32_t)e << 24);
+        }
         s = e;
     }
     for (int k = 0; k < m->n_pairs; k++) {
@@ -306,7 +317,7 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
-    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc).total;
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_size);

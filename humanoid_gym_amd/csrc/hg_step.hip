@@ -27,19 +27,63 @@
 
 namespace hg {
 
-// binary-search store so that the branch depth is log2(N), all branches wave-uniform
-template <int LO, int HI, int NA>
-HG_FI void store_at(float (&A)[NA], int i, float v) {
-    if constexpr (HI - LO == 1) {
-        A[LO] = v;
-    } else {
-        constexpr int MID = (LO + HI) / 2;
-        if (i < MID) store_at<LO, MID, NA>(A, i, v); else store_at<MID, HI, NA>(A, i, v);
-    }
-}
+// A[i] = v for a wave-uniform runtime i with compile-time register indices: a switch whose
+// cases each touch one fixed element keeps the row in VGPRs (a helper taking the array by
+// reference made hipcc leave the whole row in scratch memory).
+#define HG_ROW_CASE(I) case I: if constexpr (I < NMX) Arow[I] = qa; break;
+#define HG_ROW_SWITCH(i) switch (i) { \
+        HG_ROW_CASE(0) \
+        HG_ROW_CASE(1) \
+        HG_ROW_CASE(2) \
+        HG_ROW_CASE(3) \
+        HG_ROW_CASE(4) \
+        HG_ROW_CASE(5) \
+        HG_ROW_CASE(6) \
+        HG_ROW_CASE(7) \
+        HG_ROW_CASE(8) \
+        HG_ROW_CASE(9) \
+        HG_ROW_CASE(10) \
+        HG_ROW_CASE(11) \
+        HG_ROW_CASE(12) \
+        HG_ROW_CASE(13) \
+        HG_ROW_CASE(14) \
+        HG_ROW_CASE(15) \
+        HG_ROW_CASE(16) \
+        HG_ROW_CASE(17) \
+        HG_ROW_CASE(18) \
+        HG_ROW_CASE(19) \
+        HG_ROW_CASE(20) \
+        HG_ROW_CASE(21) \
+        HG_ROW_CASE(22) \
+        HG_ROW_CASE(23) \
+        HG_ROW_CASE(24) \
+        HG_ROW_CASE(25) \
+        HG_ROW_CASE(26) \
+        HG_ROW_CASE(27) \
+        HG_ROW_CASE(28) \
+        HG_ROW_CASE(29) \
+        HG_ROW_CASE(30) \
+        HG_ROW_CASE(31) \
+        HG_ROW_CASE(32) \
+        HG_ROW_CASE(33) \
+        HG_ROW_CASE(34) \
+        HG_ROW_CASE(35) \
+        HG_ROW_CASE(36) \
+        HG_ROW_CASE(37) \
+        HG_ROW_CASE(38) \
+        HG_ROW_CASE(39) \
+        HG_ROW_CASE(40) \
+        HG_ROW_CASE(41) \
+        HG_ROW_CASE(42) \
+        HG_ROW_CASE(43) \
+        HG_ROW_CASE(44) \
+        HG_ROW_CASE(45) \
+        HG_ROW_CASE(46) \
+        HG_ROW_CASE(47) \
+        default: break; }
 
 template <int NMX, int MAXC>
-__global__ __launch_bounds__(WAVE, 4)
+__global__ __launch_bounds__(WAVE, 3)
 void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *__restrict__ state,
                     const float *__restrict__ actions, const StepOut O)
 {
@@ -55,7 +99,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = M->n_spheres;
     const int maxlev = M->maxlev;
-    const LdsPlan L = lds_plan(n, ns, NC3);
+    const LdsPlan L = lds_plan(n, ns, NC3, maxlev);
     float *const cacheL = lds + L.cache;
     float *const jwL = lds + L.jw;
     float *const baseL = lds + L.base;     // [0:9) Rw0  [9:12) xw0  [12:48) IA0^-1
@@ -66,6 +110,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const conL = lds + L.con;
     float *const YdL = lds + L.Yd;
     float *const sdistL = lds + L.sdist;
+    int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
+    int *const bchL = nsibL + n;                                    // base_children[n]
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
     float *const upL = lds + L.AB + PUB * (n + 1);        // UP * n
     float *const JcL = lds + L.AB;                        // ndof * NC3 (after the ABA is done)
@@ -77,10 +123,15 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     // ---- per-lane link constants --------------------------------------------------
     const int li = is_link ? lane : 0;
     const float *lk = M->link[li];
-    const int par = is_link ? M->parent[li] : -1;
-    const int pidx = par < 0 ? n : par;
-    const int mylev = is_link ? M->level[li] : 0;
+    // packed topology words of this lane's link: loaded once, decoded where needed; the
+    // per-link words are read back by other lanes with v_readlane (no memory access)
+    const unsigned info_w = is_link ? M->linkinfo[li] : 0u;
+    const unsigned kids_w = is_link ? M->kids[li] : 0u;
     const int nbc = M->n_base_children;
+    if (is_link) {
+        nsibL[lane] = (int)((kids_w >> 8) & 0xffu) - 1;
+        bchL[lane] = lane < nbc ? M->base_children[lane] : -1;
+    }
 
     // ---- load state ------------------------------------------------------------------
     float q = 0.f, qd = 0.f, tgt = 0.f;
@@ -118,9 +169,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const bool is_link = lane < n;
         const int li = is_link ? lane : 0;
         const float *lk = M->link[li];
-        const int par = is_link ? M->parent[li] : -1;
+        const int par = is_link ? (int)(info_w >> 24) - 1 : -1;
         const int pidx = par < 0 ? n : par;
-        const int mylev = is_link ? M->level[li] : 0;
+        const int mylev = is_link ? (int)((info_w >> 8) & 0xffu) : 0;
+        const int first_child = (int)(kids_w & 0xffu) - 1;
         // ============ 1. kinematics, root -> leaves ============================================
         const V3 ax = ld3(lk + L_AXIS);
         const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace
@@ -169,11 +221,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (P.flags & F_GROUND) {
             #pragma unroll 1
             for (int s = lane; s < ns; s += WAVE) {
-                const int b = M->sphere_link[s];
+                const unsigned meta = M->sphere_meta[s];
+                const int b = (int)(meta & 0xffu) - 1;
                 const float *pp = pubL + PUB * (b < 0 ? n : b);
                 const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
                 const float cz = pp[11] + fmaf(pp[6], sp.x, fmaf(pp[7], sp.y, pp[8] * sp.z));
-                sdistL[s] = (M->sphere_flags[s] & 1) ? cz - sp.w : 1e30f;
+                sdistL[s] = (meta & 0x100u) ? cz - sp.w : 1e30f;
             }
             __syncthreads();
             int count = 0;
@@ -182,13 +235,15 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const int s = s0 + lane;
                 bool act = false;
                 float d = 1e30f;
+                unsigned meta = 0;
                 if (s < ns) {
                     d = sdistL[s];
                     if (d < P.margin) {
+                        meta = M->sphere_meta[s];
                         int rank = 0;
-                        const int ge = M->grp_end[s];
+                        const int ge = (int)(meta >> 24);
                         #pragma unroll 1
-                        for (int o = M->grp_begin[s]; o < ge; ++o) {
+                        for (int o = (int)((meta >> 16) & 0xffu); o < ge; ++o) {
                             const float od = sdistL[o];
                             rank += (o != s && od < P.margin && (od < d || (od == d && o < s))) ? 1 : 0;
                         }
@@ -198,7 +253,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const unsigned long long bal = __ballot(act);
                 const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
                 if (act && slot < P.maxc) {
-                    const int b = M->sphere_link[s];
+                    const int b = (int)(meta & 0xffu) - 1;
                     const float *pp = pubL + PUB * (b < 0 ? n : b);
                     const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
                     const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
@@ -241,7 +296,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         for (int lev = maxlev; lev >= 1; --lev) {
             if (is_link && mylev == lev) {
                 #pragma unroll 1
-                for (int c = M->first_child[lane]; c >= 0; c = M->next_sibling[c]) {
+                for (int c = first_child; c >= 0; c = nsibL[c]) {
                     const float *pu = upL + UP * c;
                     IA.A.xx += pu[0]; IA.A.xy += pu[1]; IA.A.xz += pu[2]; IA.A.yy += pu[3]; IA.A.yz += pu[4]; IA.A.zz += pu[5];
 #pragma unroll
@@ -296,7 +351,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             p0.l = (cross(v0.a, v0.l) - g + v0.l * (P.lin_damp + P.lin_damp * vn)) * bmass;
             #pragma unroll 1
             for (int k = 0; k < nbc; ++k) {
-                const float *pu = upL + UP * M->base_children[k];
+                const float *pu = upL + UP * bchL[k];
                 A6[0] += pu[0]; A6[1] += pu[1]; A6[2] += pu[2]; A6[7] += pu[3]; A6[8] += pu[4]; A6[14] += pu[5];
 #pragma unroll
                 for (int i = 0; i < 3; i++)
@@ -403,7 +458,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             target_err = tv - qd;
         }
         const bool row_active = row_motor || row_contact;
-        const unsigned long long myanc = (row_active && body >= 0) ? M->anc_mask[body] : 0ull;
+        // one load each: ancestor mask and packed path (ancestor-or-self per depth) of this row's body
+        unsigned long long myanc = 0ull;
+        unsigned pw[3] = {0u, 0u, 0u};
+        if (row_active && body >= 0) {
+            myanc = M->anc_mask[body];
+            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
+            pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
+        }
         __syncthreads();
 
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
@@ -418,7 +480,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int dd = DMAX; dd >= 1; --dd) {
                 float Y = 0.f;
                 if (dd <= maxlev) {      // wave-uniform
-                    const int l = (row_active && body >= 0) ? M->path[body][dd - 1] : -1;
+                    const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                     if (l >= 0) {
                         const float *pc = cacheL + CACHE * l;
                         const float f = row_motor ? (l == lane ? 1.f : 0.f) : JcL[(6 + l) * NC3 + col];
@@ -453,7 +515,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int s = 0; s < NSLOT; s++) slot[s] = ab;
             #pragma unroll 1
             for (int i = 0; i < n; ++i) {
-                const int mode = M->par_mode[i];
+                const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
+                const int mode = (int)(inf & 0xffu);
                 Sv ap = acur;
                 if (mode == 1) ap = ab;
                 else if (mode >= 2) {
@@ -462,17 +525,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 const float *pc = cacheL + CACHE * i;
                 Sv a = xmotion(ldm(pc), ld3(pc + 9), ap);
-                const int d = M->level[i];
+                const int d = (int)((inf >> 8) & 0xffu);
                 const float Y = ((myanc >> i) & 1ull) ? YdL[(d - 1) * WAVE + lane] : 0.f;
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
                 acur = a;
-                const int sv = M->save_slot[i];
+                const int sv = (int)((inf >> 16) & 0xffu) - 1;
                 if (sv >= 0) {
 #pragma unroll
                     for (int s = 0; s < NSLOT; s++) if (sv == s) slot[s] = a;
                 }
-                store_at<0, NMX, NROWS>(Arow, i, qa);
+                HG_ROW_SWITCH(i)
                 if (i == lane) diag = qa;
                 if (nc > 0) {
                     const float *jr = JcL + (6 + i) * NC3;
@@ -562,7 +625,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if (is_link && mylev == lev) {
                     Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
                     #pragma unroll 1
-                    for (int c = M->first_child[lane]; c >= 0; c = M->next_sibling[c]) Z = Z + ldsv(up6 + 8 * c);
+                    for (int c = first_child; c >= 0; c = nsibL[c]) Z = Z + ldsv(up6 + 8 * c);
                     Y = Fi - sdot(Sm, Z);
                     stsv(up6 + 8 * lane, xforce_up(E, r, sfma(U, Y * Dinv, Z)));
                 }
@@ -570,7 +633,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
             Sv Z0; Z0.a = v3(0, 0, 0); Z0.l = v3(0, 0, 0);
             #pragma unroll 1
-            for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * M->base_children[k]);
+            for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * bchL[k]);
             Z0.a = Z0.a - tmulv(Rw0, ld3(FL));
             Z0.l = Z0.l - tmulv(Rw0, ld3(FL + 3));
             float Inv[36];
