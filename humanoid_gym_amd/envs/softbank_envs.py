@@ -1,0 +1,104 @@
+"""nao-v0, pepper-v0, romeo-v0 on the MI355X simulator.
+
+Mirror /root/reference/humanoid_gym/envs/{nao,pepper,romeo}_env.py: joint name
+lists, limit / init-angle attributes, ``step`` signatures and observation
+layouts.  The robot models are the stand-ins of ``humanoid_gym_amd.robots``
+unless ``urdf_path`` points at SoftBank's real files.
+
+Step definition: the reference never calls ``stepSimulation`` for these envs
+(physics runs asynchronously at wall-clock rate under qibullet's GUI mode), so
+an env step has no deterministic length there.  Here one env step = write
+targets, ``n_substeps`` physics steps of 1/240 s (default 1), read back.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import spaces
+from ..robots import NAO_JOINTS, PEPPER_JOINTS, load_robot
+from .base import BatchedHumanoidEnv
+
+
+class _SoftbankEnv(BatchedHumanoidEnv):
+    ROBOT = ""
+
+    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, n_substeps: int = 1, **cfg_overrides):
+        model, cfg = load_robot(self.ROBOT, urdf_path)
+        for k, v in cfg_overrides.items():
+            setattr(cfg, k, v)
+        super().__init__(model, cfg, n_envs, device, n_substeps)
+        self.joint_names = [model.dof_names[k] for k in model.act_joint]
+        idx = np.asarray(model.act_joint)
+        self.lower_limits = model.lower[idx].tolist()
+        self.upper_limits = model.upper[idx].tolist()
+        self.init_angles = model.q_init[idx].tolist()
+        self.link_names = [model.dof_link_names[k] for k in model.act_joint]     # nao_env.py:40-43
+        n = len(self.joint_names)
+        self.observation_space = spaces.Box(np.array([-1] * n, dtype=np.float32), np.array([1] * n, dtype=np.float32))
+
+    def _step_sim(self, actions, joints=None):
+        if joints is None:
+            a = self._actions_tensor(actions, len(self.joint_names))
+            return self.sim.step(a, n_substeps=self.n_substeps)
+        sel = [self.model.dof_of(j) for j in joints]
+        a = self._actions_tensor(actions, len(sel))
+        return self.sim.step(a, joint_sel=sel, n_substeps=self.n_substeps)
+
+    def _dict_obs(self):
+        return {"position": self._out(self.sim.base_xyyaw) if self.batched else tuple(self.sim.base_xyyaw[0].tolist()),
+                "anglesPosition": self._out(self.sim.obs_q),
+                "anglesVelocity": self._out(self.sim.obs_qd)}
+
+    def reset(self):                      # nao_env.py:83-86: respawn in the Stand posture, returns None
+        self.sim.reset()
+
+
+class NaoEnv(_SoftbankEnv):
+    ROBOT = "nao"
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        assert self.joint_names == NAO_JOINTS                          # nao_env.py:30-31
+        self.action_space = spaces.Box(np.array(self.lower_limits, dtype=np.float32),
+                                       np.array(self.upper_limits, dtype=np.float32))
+
+    def step(self, actions, joints=None):                              # nao_env.py:48-81
+        obs, reward, done, _ = self._step_sim(actions, joints)
+        if self.batched:
+            return obs, reward, done != 0, {}
+        return self._out(obs), 0, False, {}
+
+
+class PepperEnv(_SoftbankEnv):
+    ROBOT = "pepper"
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        assert self.joint_names == PEPPER_JOINTS                       # pepper_env.py:28-39
+        # pepper_env.py:53: three extra base slots are declared but never consumed by step()
+        self.action_space = spaces.Box(np.array([-1] * 3 + self.lower_limits, dtype=np.float32),
+                                       np.array([1] * 3 + self.upper_limits, dtype=np.float32))
+
+    def step(self, actions):                                           # pepper_env.py:56-76
+        a = np.asarray(actions.cpu() if hasattr(actions, "cpu") else actions, dtype=np.float32)
+        if a.shape[-1] == len(self.joint_names) + 3:
+            a = a[..., 3:]                 # a sampled 15-D action: the base slots are ignored (base is passive)
+        obs, reward, done, _ = self._step_sim(a)
+        if self.batched:
+            return self._dict_obs(), reward, done != 0, {}
+        return self._dict_obs(), 0, False, {}
+
+
+class RomeoEnv(_SoftbankEnv):
+    ROBOT = "romeo"
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.action_space = spaces.Box(np.array(self.lower_limits, dtype=np.float32),
+                                       np.array(self.upper_limits, dtype=np.float32))
+
+    def step(self, actions):                                           # romeo_env.py:33-52
+        obs, reward, done, _ = self._step_sim(actions)
+        if self.batched:
+            return self._dict_obs(), reward, done != 0, {}
+        return self._dict_obs(), 0, False, {}

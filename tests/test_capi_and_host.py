@@ -1,0 +1,119 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/hg_sim.h
+declares; host-side logic (workloads, stats sharding, spaces).  No GPU compute here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from humanoid_gym_amd import _capi, workloads
+from humanoid_gym_amd.model import HgConfig, HgModel
+from humanoid_gym_amd.robots import load_robot
+from humanoid_gym_amd.stats import EpisodeStats, shard_range
+from humanoid_gym_amd import spaces
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "hg_sim.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(hg_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.load_library()
+    names = _declared_symbols()
+    assert set(names) == set(_capi.SYMBOLS)
+    for n in names:
+        assert getattr(L, n) is not None
+    assert L.hg_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors vs the C compiler's view of include/hg_model.h."""
+    src = '#include <stdio.h>\n#include "hg_model.h"\nint main(){printf("%zu %zu\\n", sizeof(hg_model), sizeof(hg_config));return 0;}'
+    exe = os.path.join("/tmp", "hg_sizes")
+    subprocess.run(["gcc", "-x", "c", "-I", os.path.join(ROOT, "include"), "-o", exe, "-"], input=src.encode(), check=True)
+    a, b = map(int, subprocess.check_output([exe]).split())
+    assert a == C.sizeof(HgModel) and b == C.sizeof(HgConfig)
+
+
+def test_error_paths_without_gpu():
+    import torch
+    L = _capi.load_library()
+    h = C.c_void_p()
+    assert L.hg_create(None, None, 1, 0, C.byref(h)) == -1            # HG_EINVAL
+    assert b"null" in L.hg_last_error()
+    m, cfg = load_robot("dancer")
+    cm, cc = m.to_c(), cfg.to_c()
+    assert L.hg_create(C.byref(cm), C.byref(cc), 0, 0, C.byref(h)) == -1
+    cc.max_contacts = 99
+    assert L.hg_create(C.byref(cm), C.byref(cc), 4, 0, C.byref(h)) == -1
+    if not torch.cuda.is_available():
+        cc = cfg.to_c()
+        rc = L.hg_create(C.byref(cm), C.byref(cc), 4, 0, C.byref(h))
+        assert rc == -2 and h.value is None                           # HG_ENODEVICE: no CPU fallback
+        with pytest.raises(_capi.HgError):
+            _capi.HgSim(m, cfg, 4)
+    assert L.hg_step(None, None, None, 0, 1, None, None, None, None, None, None, None) == -1
+    assert L.hg_destroy(None) == 0
+
+
+def test_replay_workload_layout():
+    m, _ = load_robot("nao")
+    l, r = workloads.synthetic_h5_trajectory(m, T=240, seed=1234)
+    assert l.shape == (240, 5) and r.shape == (240, 5) and l.dtype == np.float32
+    rows = workloads.pack_rows(l, r)                                   # h5_control_nao.py:22
+    assert rows.shape == (240, 12) and np.all(rows[:, 5] == 1) and np.all(rows[:, 11] == 1)
+    np.testing.assert_array_equal(rows[:, :5], l); np.testing.assert_array_equal(rows[:, 6:11], r)
+    names = workloads.nao_replay_joints()
+    assert len(names) == 12 and names[5] == "LHand" and names[11] == "RHand"
+    idx = [m.dof_of(n) for n in workloads.L_ARM]
+    assert np.all(l >= m.lower[idx] - 1e-6) and np.all(l <= m.upper[idx] + 1e-6)
+    path = "/tmp/hg_traj_test.npz"
+    workloads.save_trajectory(path, l, r)
+    l2, r2 = workloads.load_trajectory(path)
+    np.testing.assert_array_equal(l, l2); np.testing.assert_array_equal(r, r2)
+    a = workloads.random_actions(m, np.random.default_rng(0), 7)
+    assert a.shape == (7, 22) and np.all(a >= m.lower[m.act_joint] - 1e-6) and np.all(a <= m.upper[m.act_joint] + 1e-6)
+
+
+def test_shard_range_covers_everything_once():
+    for total, world in ((4096, 8), (10, 3), (5, 8), (0, 2)):
+        seen = []
+        for r in range(world):
+            lo, hi = shard_range(total, r, world)
+            assert 0 <= lo <= hi <= total
+            seen += list(range(lo, hi))
+        assert seen == list(range(total))
+
+
+def test_stats_single_process_cpu():
+    import torch
+    st = EpisodeStats(None, reduce_every=2, device="cpu")
+    for t in range(4):
+        st.accumulate(reward=torch.ones(5), done=torch.tensor([1, 0, 0, 0, 0]), collision=torch.tensor([1, 1, 0, 0, 0]))
+        if (t + 1) % 2 == 0:
+            st.reduce_async()
+    assert st.flush().tolist()[:4] == [20.0, 20.0, 4.0, 8.0]
+
+
+def test_stats_allreduce_world2_gloo():
+    """The N > 1 path: two ranks, disjoint env slices, gloo all-reduce of the 8-float vector."""
+    script = os.path.join(ROOT, "tests", "_gloo_stats_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531", script],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GLOO_STATS_OK" in out.stdout
+
+
+def test_box_space_fallback():
+    b = spaces.Box(np.array([-1.0, 0.0], dtype=np.float32), np.array([1.0, 2.0], dtype=np.float32))
+    for _ in range(10):
+        assert b.contains(b.sample())

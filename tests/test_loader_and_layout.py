@@ -1,0 +1,134 @@
+"""Integer half of the contract: joint/link index maps, topology, name lists (bit-exact)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from humanoid_gym_amd.model import FlatModel
+from humanoid_gym_amd.robots import NAO_JOINTS, PEPPER_JOINTS, load_robot
+from humanoid_gym_amd.urdf import load_urdf, principal_axes, quat_to_mat, mat_to_quat, rpy_to_mat
+import humanoid_gym_amd as hg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "dancer_layout.json")))
+REF_URDF = "/root/reference/humanoid_gym/envs/assets/dancer/dancer_urdf_model.URDF"
+
+
+def test_dancer_maps_match_golden():
+    m, cfg = load_robot("dancer")
+    assert m.joint_names_all == GOLD["joint_names"]
+    assert m.link_names_all == GOLD["link_names"]
+    assert m.parent.tolist() == GOLD["parent_index"]
+    assert m.base_link == GOLD["base_link"]
+    assert m.joint2Index == {n: i for i, n in enumerate(GOLD["joint_names"])}     # dancer_env.py:77
+    assert m.link2Index == {n: i for i, n in enumerate(GOLD["link_names"])}       # dancer_env.py:79
+    assert m.n_links == 18 and m.n_act == 18
+    assert abs(m.total_mass() - GOLD["total_mass"]) < 1e-12
+    # world parameters: dancer_env.py:63-65
+    assert cfg.gravity == (0.0, 0.0, -10.0) and cfg.solver_iters == 150 and abs(cfg.dt - 1 / 240) < 1e-15
+
+
+def test_dancer_axes_and_reset_pose():
+    m, _ = load_robot("dancer")
+    # joint axes are stored in the internal (principal-axis) frame: rotate back to the URDF link frame
+    for i, ax in enumerate(GOLD["axis"]):
+        R_int_to_link = quat_to_mat(m.frame_quat[i + 1]).T
+        a = R_int_to_link @ m.axis[i]
+        g = np.array(ax) / np.linalg.norm(ax)
+        assert np.abs(a - g).max() < 1e-9, i
+    # reset pose: whole-body COM and lowest mesh corner computed in the survey
+    n = m.n_links
+    Rb, xb = quat_to_mat(m.base_quat0), m.base_pos0
+    Rw, xw = [None] * n, [None] * n
+    for i in range(n):
+        p = m.parent[i]
+        Rp, xp = (Rb, xb) if p < 0 else (Rw[p], xw[p])
+        Rw[i] = Rp @ m.R0[i].T
+        xw[i] = xp + Rp @ m.d[i] + Rw[i] @ m.e[i]
+    com = (m.base_mass * xb + sum(m.mass[i] * xw[i] for i in range(n))) / m.total_mass()
+    assert np.abs(com - np.array(GOLD["reset_com"])).max() < 1e-4
+    zs = [((xb if b < 0 else xw[b]) + (Rb if b < 0 else Rw[b]) @ m.sphere_pos[s])[2] - m.sphere_radius[s]
+          for s, b in enumerate(m.sphere_link)]
+    assert abs(min(zs) - GOLD["reset_lowest_z"]) < 1e-4
+    # base link frame sits where loadURDF was told to put it (dancer_env.py:59)
+    Rl = Rb @ quat_to_mat(m.frame_quat[0])
+    pl = xb + Rb @ m.frame_pos[0]
+    assert np.abs(pl - np.array([-0.3, -0.3, 0.3])).max() < 1e-12
+    assert np.abs(Rl - np.array([[-1, 0, 0], [0, 0, -1], [0, -1, 0]])).max() < 1e-6
+
+
+@pytest.mark.skipif(not os.path.exists(REF_URDF), reason="reference tree not present (GPU box)")
+def test_shipped_dancer_json_equals_fresh_flatten():
+    fresh = load_urdf(REF_URDF, base_position=[-0.3, -0.3, 0.3], base_orientation=[0, 0.7071068, -0.7071068, 0],
+                      self_collision=True, name="dancer")
+    shipped, _ = load_robot("dancer")
+    for k in FlatModel._ARRAYS:
+        np.testing.assert_array_equal(np.asarray(getattr(fresh, k)), np.asarray(getattr(shipped, k)), err_msg=k)
+    assert fresh.meta["missing_meshes"] == ["body_chest"]      # .MISSING_LARGE_BLOBS
+
+
+def test_self_collision_pairs_exclude_all_parents():
+    m, _ = load_robot("dancer")
+    anc = [set() for _ in range(m.n_links)]
+    for k in range(m.n_links):
+        p = m.parent[k]
+        while p >= 0:
+            anc[k].add(int(p)); p = m.parent[p]
+    assert len(m.pair_a) > 0
+    for a, b in zip(m.pair_a, m.pair_b):
+        la, lb = m.sphere_link[a], m.sphere_link[b]
+        assert la != lb and la not in anc[lb] and lb not in anc[la] and la >= 0 and lb >= 0
+
+
+def test_softbank_like_name_orders():
+    nao, cfg = load_robot("nao")
+    assert NAO_JOINTS == GOLD["nao"] and PEPPER_JOINTS == GOLD["pepper"]
+    assert [nao.dof_names[k] for k in nao.act_joint] == GOLD["nao"]               # nao_env.py:30-31
+    pep, _ = load_robot("pepper")
+    assert [pep.dof_names[k] for k in pep.act_joint] == GOLD["pepper"]            # pepper_env.py:28-39
+    rom, _ = load_robot("romeo")
+    assert all("Finger" not in n and "Thumb" not in n for n in rom.dof_names)     # romeo_env.py:25
+    assert rom.n_act == rom.n_links == 37
+    assert cfg.gravity[2] == -9.81 and cfg.solver_iters == 50
+    for m in (nao, pep, rom):
+        idx = np.asarray(m.act_joint)
+        assert np.all(m.lower[idx] <= m.q_init[idx]) and np.all(m.q_init[idx] <= m.upper[idx])
+        assert np.all(m.parent < np.arange(m.n_links))
+
+
+def test_env_ids_match_reference_registration():
+    sim_ids = [i for i in GOLD["env_ids"] if i != "nao-real-v0"]                  # hardware env: out of scope
+    assert sorted(hg.ENTRY_POINTS) == sorted(sim_ids)
+
+
+def test_json_roundtrip_and_cstruct():
+    m, _ = load_robot("nao")
+    m2 = FlatModel.from_json(m.to_json())
+    for k in FlatModel._ARRAYS:
+        np.testing.assert_array_equal(np.asarray(getattr(m, k)), np.asarray(getattr(m2, k)))
+    c = m.to_c()
+    assert c.n_links == 26 and c.n_act == 22 and c.parent[0] == -1
+
+
+def test_rotation_helpers():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        R = rpy_to_mat(rng.uniform(-3, 3, 3))
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+        assert np.abs(quat_to_mat(mat_to_quat(R)) - R).max() < 1e-12
+        A = rng.normal(size=(3, 3)); I = A @ A.T + np.eye(3)
+        mom, V = principal_axes(I)
+        assert np.abs(V @ np.diag(mom) @ V.T - I).max() < 1e-5 * np.abs(I).max()
+        assert abs(np.linalg.det(V) - 1) < 1e-9
+    mom, V = principal_axes(np.diag([1.0, 2.0, 3.0]))
+    assert mom.tolist() == [1.0, 2.0, 3.0] and np.array_equal(V, np.eye(3))      # diagonal input untouched
+
+
+def test_ragged_and_edge_inputs():
+    m, _ = load_robot("dancer")
+    m.parent = m.parent.copy(); m.parent[3] = 5                                   # child before parent
+    with pytest.raises(ValueError):
+        m.check()
+    with pytest.raises(KeyError):
+        load_robot("atlas")
