@@ -43,6 +43,7 @@ struct DevModel {
     uint32_t kids[HG_MAX_LINKS];        // (first_child + 1) | (next_sibling + 1) << 8
     uint32_t pathw[HG_MAX_LINKS][4];    // byte d-1 of the 16: path[b][d-1] + 1 (0 = none)
     uint32_t sphere_meta[HG_MAX_SPHERES]; // (link + 1) | flags << 8 | grp_begin << 16 | grp_end << 24
+    uint32_t pair_meta[HG_MAX_PAIRS];     // sphere a | sphere b << 8 | (link a + 1) << 16 | (link b + 1) << 24
     unsigned long long anc_mask[HG_MAX_LINKS];  // bit j: j is b or an ancestor of b
     float   link[HG_MAX_LINKS][LINKC];
     float   base[32];
@@ -75,10 +76,10 @@ struct StepOut {
 
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd, sdist, tab, AB, total;
+    int cache, jw, base, vel, F, lam, misc, con, Yd, Yd2, sdist, scen, tab, AB, total;
 };
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, bool self) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
@@ -91,7 +92,9 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev) 
     p.misc = o;  o += 64;
     p.con = o;   o += CON * HG_MAX_CONTACTS;
     p.Yd = o;    o += maxlev * WAVE;
+    p.Yd2 = o;   o += self ? maxlev * WAVE : 0;
     p.sdist = o; o += rup4(ns);
+    p.scen = o;  o += self ? 4 * ns : 0;
     p.tab = o;   o += rup4(2 * n);          // int tables: next_sibling[n], base_children[n]
     p.AB = o;
     int a = PUB * (n + 1) + UP * n;

@@ -261,6 +261,9 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
             *why = "self-collision pair out of range"; return HG_EINVAL;
         }
         D->pair_a[k] = (int16_t)m->pair_a[k]; D->pair_b[k] = (int16_t)m->pair_b[k];
+        D->pair_meta[k] = (uint32_t)m->pair_a[k] | ((uint32_t)m->pair_b[k] << 8) |
+                          ((uint32_t)(uint8_t)(m->sphere_link[m->pair_a[k]] + 1) << 16) |
+                          ((uint32_t)(uint8_t)(m->sphere_link[m->pair_b[k]] + 1) << 24);
     }
     return HG_OK;
 }
@@ -295,7 +298,6 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
         return fail(HG_EINVAL, "hg_create: model sizes out of range");
     if (config->max_contacts < 0 || config->max_contacts > HG_MAX_CONTACTS || config->solver_iters < 0 || !(config->dt > 0))
         return fail(HG_EINVAL, "hg_create: bad config (max_contacts, solver_iters or dt)");
-    if (config->enable_self) return fail(HG_EUNSUPPORTED, "hg_create: self-collision rows are not built yet");
     int variant = -1;
     for (int v = 0; v < kNumVariants; v++)
         if (kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts) { variant = v; break; }
@@ -317,7 +319,7 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
-    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev).total;
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, config->enable_self != 0).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_size);
@@ -378,7 +380,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     const hg_config &c = s->cfg;
     P.n_envs = s->n_envs; P.n_substeps = n_substeps; P.iters = c.solver_iters; P.maxc = c.max_contacts;
     P.n_sel = n_sel;
-    P.flags = (c.enable_ground ? F_GROUND : 0) | (c.clamp_targets ? F_CLAMP : 0) |
+    P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0);
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];

@@ -99,7 +99,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = M->n_spheres;
     const int maxlev = M->maxlev;
-    const LdsPlan L = lds_plan(n, ns, NC3, maxlev);
+    const LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
     float *const cacheL = lds + L.cache;
     float *const jwL = lds + L.jw;
     float *const baseL = lds + L.base;     // [0:9) Rw0  [9:12) xw0  [12:48) IA0^-1
@@ -110,6 +110,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const conL = lds + L.con;
     float *const YdL = lds + L.Yd;
     float *const sdistL = lds + L.sdist;
+    float *const scenL = lds + L.scen;       // sphere centres + radius, only with self-collision
+    float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, only with self-collision
     int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
     int *const bchL = nsibL + n;                                    // base_children[n]
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
@@ -218,51 +220,86 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ============ 2. contact detection on the current pose =================================
         nc = 0;
         link_mask = 0;
-        if (P.flags & F_GROUND) {
+        if (P.flags & (F_GROUND | F_SELF)) {
             #pragma unroll 1
             for (int s = lane; s < ns; s += WAVE) {
                 const unsigned meta = M->sphere_meta[s];
                 const int b = (int)(meta & 0xffu) - 1;
                 const float *pp = pubL + PUB * (b < 0 ? n : b);
                 const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
-                const float cz = pp[11] + fmaf(pp[6], sp.x, fmaf(pp[7], sp.y, pp[8] * sp.z));
-                sdistL[s] = (meta & 0x100u) ? cz - sp.w : 1e30f;
+                const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
+                sdistL[s] = ((meta & 0x100u) && (P.flags & F_GROUND)) ? c.z - sp.w : 1e30f;
+                if (P.flags & F_SELF) { st3(scenL + 4 * s, c); scenL[4 * s + 3] = sp.w; }
             }
             __syncthreads();
             int count = 0;
-            #pragma unroll 1
-            for (int s0 = 0; s0 < ns; s0 += WAVE) {
-                const int s = s0 + lane;
-                bool act = false;
-                float d = 1e30f;
-                unsigned meta = 0;
-                if (s < ns) {
-                    d = sdistL[s];
-                    if (d < P.margin) {
-                        meta = M->sphere_meta[s];
-                        int rank = 0;
-                        const int ge = (int)(meta >> 24);
-                        #pragma unroll 1
-                        for (int o = (int)((meta >> 16) & 0xffu); o < ge; ++o) {
-                            const float od = sdistL[o];
-                            rank += (o != s && od < P.margin && (od < d || (od == d && o < s))) ? 1 : 0;
+            if (P.flags & F_GROUND) {
+                #pragma unroll 1
+                for (int s0 = 0; s0 < ns; s0 += WAVE) {
+                    const int s = s0 + lane;
+                    bool act = false;
+                    float d = 1e30f;
+                    unsigned meta = 0;
+                    if (s < ns) {
+                        d = sdistL[s];
+                        if (d < P.margin) {
+                            meta = M->sphere_meta[s];
+                            int rank = 0;
+                            const int ge = (int)(meta >> 24);
+                            #pragma unroll 1
+                            for (int o = (int)((meta >> 16) & 0xffu); o < ge; ++o) {
+                                const float od = sdistL[o];
+                                rank += (o != s && od < P.margin && (od < d || (od == d && o < s))) ? 1 : 0;
+                            }
+                            act = rank < 4;
                         }
-                        act = rank < 4;
                     }
+                    const unsigned long long bal = __ballot(act);
+                    const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (act && slot < P.maxc) {
+                        const int b = (int)(meta & 0xffu) - 1;
+                        const float *pp = pubL + PUB * (b < 0 ? n : b);
+                        const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
+                        const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
+                        float *co = conL + CON * slot;
+                        co[0] = __int_as_float(b); co[1] = __int_as_float(-2);
+                        co[2] = c.x; co[3] = c.y; co[4] = d;
+                        co[5] = 0.f; co[6] = 0.f; co[7] = 1.f; co[8] = d;
+                    }
+                    count += __popcll(bal);
                 }
-                const unsigned long long bal = __ballot(act);
-                const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
-                if (act && slot < P.maxc) {
-                    const int b = (int)(meta & 0xffu) - 1;
-                    const float *pp = pubL + PUB * (b < 0 ? n : b);
-                    const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
-                    const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
-                    float *co = conL + CON * slot;
-                    co[0] = __int_as_float(b); co[1] = __int_as_float(-2);
-                    co[2] = c.x; co[3] = c.y; co[4] = d;
-                    co[5] = 0.f; co[6] = 0.f; co[7] = 1.f; co[8] = d;
+            }
+            if (P.flags & F_SELF) {
+                // sphere pairs of bodies that are not ancestors of one another, in pair order
+                const int np = M->n_pairs;
+                #pragma unroll 1
+                for (int p0 = 0; p0 < np && count < P.maxc; p0 += WAVE) {
+                    const int p = p0 + lane;
+                    bool act = false;
+                    unsigned pr = 0;
+                    V3 d = v3(0, 0, 0), ca = d, cb = d;
+                    float len = 1.f, ds = 0.f, ra = 0.f, rb = 0.f;
+                    if (p < np) {
+                        pr = M->pair_meta[p];
+                        const float *pa = scenL + 4 * (pr & 0xffu), *pb = scenL + 4 * ((pr >> 8) & 0xffu);
+                        ca = ld3(pa); cb = ld3(pb); ra = pa[3]; rb = pb[3];
+                        d = ca - cb;
+                        len = sqrtf(dot(d, d));
+                        ds = len - ra - rb;
+                        act = ds < P.margin && len >= 1e-9f;
+                    }
+                    const unsigned long long bal = __ballot(act);
+                    const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (act && slot < P.maxc) {
+                        const V3 nrm = d * (1.0f / len);
+                        const V3 pt = ((ca - nrm * ra) + (cb + nrm * rb)) * 0.5f;
+                        float *co = conL + CON * slot;
+                        co[0] = __int_as_float((int)((pr >> 16) & 0xffu) - 1);
+                        co[1] = __int_as_float((int)((pr >> 24) & 0xffu) - 1);
+                        st3(co + 2, pt); st3(co + 5, nrm); co[8] = ds;
+                    }
+                    count += __popcll(bal);
                 }
-                count += __popcll(bal);
             }
             nc = count < P.maxc ? count : P.maxc;
         }
@@ -408,15 +445,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const bool row_contact = cidx >= 0 && cidx < nc;
         const bool row_motor = is_link;                  // NMX >= n by construction
         int body = row_motor ? lane : -1;
+        int body2 = -3;                                  // second body of a self-contact row, else < -1
         float target_err = 0.f;                          // desired change of J.v
         V3 Jang = v3(0, 0, 0), Jlin = v3(0, 0, 0);
         if (nc > 0) {
             V3 pt = v3(0, 0, 0), dir = v3(0, 0, 0);
             float dist = 0.f;
-            unsigned long long anc = 0;
+            unsigned long long anc = 0, anc2 = 0;
             if (row_contact) {
                 const float *co = conL + CON * cidx;
                 body = __float_as_int(co[0]);
+                body2 = __float_as_int(co[1]);
                 pt = ld3(co + 2);
                 const V3 nrm = ld3(co + 5);
                 dist = co[8];
@@ -424,8 +463,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 plane_space(nrm, t1, t2);
                 dir = col < MAXC ? nrm : (((col - MAXC) & 1) ? t2 : t1);
                 anc = body >= 0 ? M->anc_mask[body] : 0ull;
-                Jang = cross(pt - bpos, dir);
-                Jlin = dir;
+                if (body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
+                    anc2 = body2 >= 0 ? M->anc_mask[body2] : 0ull;
+                } else {
+                    Jang = cross(pt - bpos, dir);
+                    Jlin = dir;
+                }
             }
             float rv = 0.f;
             if (col >= 0) {
@@ -433,7 +476,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 for (int i = 0; i < n; ++i) {
                     const float *pj = jwL + 8 * i;
                     float j = 0.f;
-                    if ((anc >> i) & 1ull) j = dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                    const int sg = (int)((anc >> i) & 1ull) - (int)((anc2 >> i) & 1ull);
+                    if (sg != 0) j = (float)sg * dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
                     JcL[(6 + i) * NC3 + col] = j;
                     rv = fmaf(j, velL[6 + i], rv);
                 }
@@ -459,13 +503,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         const bool row_active = row_motor || row_contact;
         // one load each: ancestor mask and packed path (ancestor-or-self per depth) of this row's body
-        unsigned long long myanc = 0ull;
-        unsigned pw[3] = {0u, 0u, 0u};
+        unsigned long long myanc = 0ull, myanc2 = 0ull;
+        unsigned pw[3] = {0u, 0u, 0u}, pw2[3] = {0u, 0u, 0u};
         if (row_active && body >= 0) {
             myanc = M->anc_mask[body];
             const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
             pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
         }
+        if (row_contact && body2 >= 0) {
+            myanc2 = M->anc_mask[body2];
+            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body2]);
+            pw2[0] = t.x; pw2[1] = t.y; pw2[2] = t.z;
+        }
+        const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
         __syncthreads();
 
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
@@ -491,6 +541,28 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     }
                     YdL[(dd - 1) * WAVE + lane] = Y;
                 }
+            }
+            if (two_body) {
+                // The impulse of a self-contact row acts on two branches.  By linearity the second
+                // branch is walked on its own (its force entries are already in Jc with their sign);
+                // the zero-acceleration forces meet at the base.
+                Sv Z2; Z2.a = v3(0, 0, 0); Z2.l = v3(0, 0, 0);
+#pragma unroll
+                for (int dd = DMAX; dd >= 1; --dd) {
+                    float Y = 0.f;
+                    if (dd <= maxlev) {
+                        const int l = (int)((pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        if (l >= 0) {
+                            const float *pc = cacheL + CACHE * l;
+                            // entries of links shared with the first branch are zero in Jc (they cancel)
+                            const float f = ((myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];
+                            Y = f - sdot(ldsv(pc + 20), Z2);
+                            Z2 = xforce_up(ldm(pc), ld3(pc + 9), sfma(ldsv(pc + 12), Y * pc[18], Z2));
+                        }
+                        Yd2L[(dd - 1) * WAVE + lane] = Y;
+                    }
+                }
+                Z = Z + Z2;
             }
             // (ii) base
             const M3 Rb = ldm(baseL);
@@ -526,7 +598,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const float *pc = cacheL + CACHE * i;
                 Sv a = xmotion(ldm(pc), ld3(pc + 9), ap);
                 const int d = (int)((inf >> 8) & 0xffu);
-                const float Y = ((myanc >> i) & 1ull) ? YdL[(d - 1) * WAVE + lane] : 0.f;
+                float Y = ((myanc >> i) & 1ull) ? YdL[(d - 1) * WAVE + lane] : 0.f;
+                if (two_body && ((myanc2 >> i) & 1ull)) Y += Yd2L[(d - 1) * WAVE + lane];
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
                 acur = a;

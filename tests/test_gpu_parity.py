@@ -161,3 +161,39 @@ def test_reset_mask_and_substeps():
             assert np.abs(after[e] - fresh).max() < 1e-6
         else:
             np.testing.assert_array_equal(after[e], before[e])
+
+
+def test_dancer_self_collision_rows():
+    """URDF_USE_SELF_COLLISION (dancer_env.py:60): at q = 0 the two feet overlap -- the reason the
+    reference nudges init_angles[7], [13] -- so self-contact rows are active from the first step."""
+    n_envs = 4
+    model, cfg, gpu, cpu, torch = _mk("dancer", n_envs, enable_self=True)
+    rng = np.random.default_rng(5)
+    act = np.zeros((n_envs, model.n_act))
+    act[:, 7], act[:, 13] = 0.4, -0.4
+    act[1:] += rng.uniform(-0.3, 0.3, (n_envs - 1, model.n_act))
+    ta = torch.tensor(act, dtype=torch.float32, device="cuda:0")
+    saw_self = False
+    worst = np.zeros(n_envs)
+    same = 0
+    for t in range(100):
+        o = cpu.step(act)
+        gq, _, _, gcol = gpu.step(ta)
+        pairs, counts, mask = gpu.contact_pairs()
+        c, p = counts.cpu().numpy(), pairs.cpu().numpy()
+        worst = np.maximum(worst, np.abs(gq.cpu().numpy() - o["q"]).max(1))
+        if t < 12:      # before trajectories can separate: integer outputs must be identical
+            np.testing.assert_array_equal(c, o["n_contacts"], err_msg=f"step {t}")
+            np.testing.assert_array_equal(p, o["pairs"], err_msg=f"step {t}")
+            np.testing.assert_array_equal(mask.cpu().numpy().astype(np.uint64), o["link_mask"])
+            assert worst.max() < 1e-3
+        same += int(sum(np.array_equal(p[e], o["pairs"][e]) for e in range(n_envs)))
+        saw_self |= bool(((p[..., 1] >= 0) & (p[..., 0] >= 0)).any())
+    # Bounded drift under contact: deeply overlapping foot spheres make the contact normals
+    # ill-conditioned, so single envs may wander; most stay tight and all stay bounded.
+    assert np.median(worst) < 2e-3 and worst.max() < 0.15, worst
+    assert same >= 0.9 * 100 * n_envs
+    assert saw_self
+    assert set(map(tuple, o["pairs"][0, :o["n_contacts"][0]].tolist())) >= {(11, 17)}
+    st = gpu.get_state().cpu().numpy()
+    assert np.isfinite(st).all() and np.abs(st[:, :3] - cpu.state[:, :3]).max() < 2e-2
