@@ -27,6 +27,15 @@
 
 namespace hg {
 
+// The workgroup is ONE wavefront, whose LDS operations execute in program order, so lanes can
+// hand data to each other through LDS without s_barrier (which would also drain vmcnt).  What is
+// still needed is that hipcc does not move LDS accesses across the hand-off point.
+HG_FI void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // A[i] = v for a wave-uniform runtime i with compile-time register indices: a switch whose
 // cases each touch one fixed element keeps the row in VGPRs (a helper taking the array by
 // reference made hipcc leave the whole row in scratch memory).
@@ -144,17 +153,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     // ---- targets (dancer_env.py:19 / nao_env.py:70) --------------------------------------
     if (P.flags & F_ACTIONS) {
         if (is_link) miscL[lane] = tgt;
-        __syncthreads();
+        wave_sync();
         int mysel = 0;
         #pragma unroll 1
         for (int k = 0; k < P.n_sel; ++k) if (lane == k) mysel = P.sel[k];
         if (lane < P.n_sel) miscL[mysel] = actions[(size_t)env * P.n_sel + lane];
-        __syncthreads();
+        wave_sync();
         if (is_link) {
             tgt = miscL[lane];
             if (P.flags & F_CLAMP) tgt = fminf(fmaxf(tgt, lk[L_LOWER]), lk[L_UPPER]);
         }
-        __syncthreads();
+        wave_sync();
     }
 
     int nc = 0;                       // contacts of the current physics step
@@ -196,7 +205,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 stm(baseL, Rw0); st3(baseL + 9, bpos);
             }
         }
-        __syncthreads();
+        wave_sync();
         Sv v = v0;
         V3 gl = v3(0, 0, 0);                   // gravity in the link frame
         #pragma unroll 1
@@ -214,7 +223,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 st3(pj, mulv(Rw, ax));
                 st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
             }
-            __syncthreads();
+            wave_sync();
         }
 
         // ============ 2. contact detection on the current pose =================================
@@ -231,7 +240,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 sdistL[s] = ((meta & 0x100u) && (P.flags & F_GROUND)) ? c.z - sp.w : 1e30f;
                 if (P.flags & F_SELF) { st3(scenL + 4 * s, c); scenL[4 * s + 3] = sp.w; }
             }
-            __syncthreads();
+            wave_sync();
             int count = 0;
             if (P.flags & F_GROUND) {
                 #pragma unroll 1
@@ -368,7 +377,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 float *pc = cacheL + CACHE * lane;
                 stm(pc, E); st3(pc + 9, r); stsv(pc + 12, U); pc[18] = Dinv; stsv(pc + 20, Sm);
             }
-            __syncthreads();
+            wave_sync();
         }
         // base (every lane computes the same thing; results stay in registers)
         Sv a0;
@@ -413,7 +422,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 stsv(pubL + PUB * n + 12, a0);
             }
         }
-        __syncthreads();
+        wave_sync();
         // root -> leaves: accelerations
         float qdd = 0.f;
         #pragma unroll 1
@@ -424,7 +433,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 a = sfma(Sm, qdd, a);
                 stsv(pubL + PUB * lane + 12, a);
             }
-            __syncthreads();
+            wave_sync();
         }
         // velocities += dt * unconstrained acceleration
         qd = fmaf(P.dt, qdd, qd);
@@ -438,7 +447,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // world-frame joint axes and pivots for the contact Jacobians, current velocities
         if (is_link) velL[6 + lane] = qd;
         if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
-        __syncthreads();      // region AB (pub/up) is dead from here on: Jc may overwrite it
+        wave_sync();      // region AB (pub/up) is dead from here on: Jc may overwrite it
 
         const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
         const int cidx = col < 0 ? -1 : (col < MAXC ? col : (col - MAXC) >> 1);
@@ -516,7 +525,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             pw2[0] = t.x; pw2[1] = t.y; pw2[2] = t.z;
         }
         const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
-        __syncthreads();
+        wave_sync();
 
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
         float Arow[NROWS];
@@ -670,7 +679,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
         lamL[lane] = lam;
-        __syncthreads();      // all reads of Jc by other lanes' Arow accumulation are done as well
+        wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
         if (lane < ndof) {
             float f = lane >= 6 ? lamL[lane - 6] : 0.f;
             if (nc > 0) {
@@ -680,7 +689,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
             FL[lane] = f;
         }
-        __syncthreads();      // Jc is dead: region AB is reused for the 6-float exchanges below
+        wave_sync();      // Jc is dead: region AB is reused for the 6-float exchanges below
         {
             float *const up6 = lds + L.AB;             // 8 * n
             float *const pub6 = lds + L.AB + 8 * n;    // 8 * (n + 1)
@@ -702,7 +711,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     Y = Fi - sdot(Sm, Z);
                     stsv(up6 + 8 * lane, xforce_up(E, r, sfma(U, Y * Dinv, Z)));
                 }
-                __syncthreads();
+                wave_sync();
             }
             Sv Z0; Z0.a = v3(0, 0, 0); Z0.l = v3(0, 0, 0);
             #pragma unroll 1
@@ -714,7 +723,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int k = 0; k < 36; k++) Inv[k] = baseL[12 + k];
             const Sv ab = neg_mul6(Inv, Z0);
             if (lane == 0) stsv(pub6 + 8 * n, ab);
-            __syncthreads();
+            wave_sync();
             float dq = 0.f;
             #pragma unroll 1
             for (int lev = 1; lev <= maxlev; ++lev) {
@@ -724,7 +733,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     a = sfma(Sm, dq, a);
                     stsv(pub6 + 8 * lane, a);
                 }
-                __syncthreads();
+                wave_sync();
             }
             qd += dq;
             bang = bang + mulv(Rw0, ab.a);
@@ -751,7 +760,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
             for (int k = 0; k < 4; k++) bq[k] = nq[k] * inv;
         }
-        __syncthreads();
+        wave_sync();
     }  // substeps
 
     // ---- non-finite guard: reset the env in place and raise done ---------------------------------
@@ -774,7 +783,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 
     // ---- observations and flags (dancer_env.py:32-35,51-52; pepper_env.py:64-68) -----------------
     if (is_link) { miscL[lane] = q; velL[lane] = qd; }
-    __syncthreads();
+    wave_sync();
     const int na = M->n_act;
     if (lane < na) {
         const int j = M->act_joint[lane];
