@@ -75,10 +75,12 @@ struct StepOut {
 };
 
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
+// vel/F and lam/misc share storage (never live together); region AB is time-shared, see hg_step.hip.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd, Yd2, sdist, scen, tab, AB, total;
+    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, AB, acc, total;
 };
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, bool self) {
     LdsPlan p;
     int o = 0;
@@ -86,20 +88,15 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.cache = o; o += CACHE * n;
     p.jw = o;    o += 8 * n;
     p.base = o;  o += 64;
-    p.vel = o;   o += ndof;
-    p.F = o;     o += ndof;
-    p.lam = o;   o += 64;
-    p.misc = o;  o += 64;
-    p.con = o;   o += CON * HG_MAX_CONTACTS;
-    p.Yd = o;    o += maxlev * WAVE;
+    p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
+    p.lam = o;   p.misc = o; o += 64;
+    p.con = o;   o += CON * (nc3 / 3);
     p.Yd2 = o;   o += self ? maxlev * WAVE : 0;
     p.sdist = o; o += rup4(ns);
     p.scen = o;  o += self ? 4 * ns : 0;
     p.tab = o;   o += rup4(2 * n);          // int tables: next_sibling[n], base_children[n]
-    p.AB = o;
-    int a = PUB * (n + 1) + UP * n;
-    int b = (6 + n) * nc3;
-    o += rup4(a > b ? a : b);
+    p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
+    p.acc = o;   o += 8 * (n + 1);
     p.total = o;
     return p;
 }

@@ -158,9 +158,18 @@ struct hg_sim {
 
 namespace hg {
 
-struct Variant { int nmx, maxc; };
-static const Variant kVariants[] = {{18, 12}, {28, 12}, {40, 8}, {46, 6}};
-constexpr int kNumVariants = 4;
+// kernel instantiations: motor lanes, contact slots, tree depth, branch slots, waves per SIMD
+struct Variant { int nmx, maxc, depth, nsl, wpe; };
+#define HG_VARIANTS(X) \
+    X(0, 18, 12, 6, 0, 4)  /* dancer                                   */ \
+    X(1, 28, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
+    X(2, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
+    X(3, 28, 12, 12, 2, 3) /* pepper (deep chain, branching torso)     */ \
+    X(4, 40, 8, 12, 2, 3)  /* romeo                                    */ \
+    X(5, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
+#define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
+static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, std::string *why) {
     const int n = m->n_links;
@@ -268,9 +277,9 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
     return HG_OK;
 }
 
-template <int NMX, int MAXC>
+template <int NMX, int MAXC, int DEPTH, int NSL, int WPE>
 static hipError_t launch_step(const hg_sim *s, const StepParams &P, const float *actions, const StepOut &O, hipStream_t st) {
-    hipLaunchKernelGGL((hg_step_kernel<NMX, MAXC>), dim3(s->n_envs), dim3(WAVE), s->lds_bytes, st,
+    hipLaunchKernelGGL((hg_step_kernel<NMX, MAXC, DEPTH, NSL, WPE>), dim3(s->n_envs), dim3(WAVE), s->lds_bytes, st,
                        s->d_model, P, s->d_state, actions, O);
     return hipGetLastError();
 }
@@ -298,10 +307,6 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
         return fail(HG_EINVAL, "hg_create: model sizes out of range");
     if (config->max_contacts < 0 || config->max_contacts > HG_MAX_CONTACTS || config->solver_iters < 0 || !(config->dt > 0))
         return fail(HG_EINVAL, "hg_create: bad config (max_contacts, solver_iters or dt)");
-    int variant = -1;
-    for (int v = 0; v < kNumVariants; v++)
-        if (kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts) { variant = v; break; }
-    if (variant < 0) return fail(HG_EUNSUPPORTED, "hg_create: no kernel variant for this (n_links, max_contacts)");
 
     int ndev = 0;
     HG_HIP(hipGetDeviceCount(&ndev));
@@ -313,6 +318,14 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     std::string why;
     int rc = build_dev_model(model, config, hm, &why);
     if (rc) { delete hm; return fail(rc, "hg_create: " + why); }
+    int variant = -1;
+    for (int v = 0; v < kNumVariants; v++)
+        if (kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts &&
+            kVariants[v].depth >= hm->maxlev && kVariants[v].nsl >= hm->n_slots) { variant = v; break; }
+    if (variant < 0) {
+        delete hm;
+        return fail(HG_EUNSUPPORTED, "hg_create: no kernel variant for this (n_links, max_contacts, tree depth, branching)");
+    }
 
     hg_sim *s = new (std::nothrow) hg_sim;
     if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }
@@ -394,10 +407,9 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
     switch (s->variant) {
-        case 0: e = launch_step<18, 12>(s, P, actions_dev, O, st); break;
-        case 1: e = launch_step<28, 12>(s, P, actions_dev, O, st); break;
-        case 2: e = launch_step<40, 8>(s, P, actions_dev, O, st); break;
-        default: e = launch_step<46, 6>(s, P, actions_dev, O, st); break;
+#define HG_VARIANT_CASE(i, a, b, c, d, w) case i: e = launch_step<a, b, c, d, w>(s, P, actions_dev, O, st); break;
+        HG_VARIANTS(HG_VARIANT_CASE)
+        default: return fail(HG_EUNSUPPORTED, "hg_step: bad kernel variant");
     }
     if (e != hipSuccess) return fail(HG_ENODEVICE, std::string("hg_step: launch failed: ") + hipGetErrorString(e));
     return HG_OK;

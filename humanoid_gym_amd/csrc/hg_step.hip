@@ -91,8 +91,10 @@ HG_FI void wave_sync() {
         HG_ROW_CASE(47) \
         default: break; }
 
-template <int NMX, int MAXC>
-__global__ __launch_bounds__(WAVE, 3)
+// NMX: motor-row lanes (>= n dofs), MAXC: contact slots, DEPTH: deepest link level handled,
+// NSL: saved-acceleration slots for branching links, WPE: waves per SIMD the register budget targets.
+template <int NMX, int MAXC, int DEPTH, int NSL, int WPE>
+__global__ __launch_bounds__(WAVE, WPE)
 void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *__restrict__ state,
                     const float *__restrict__ actions, const StepOut O)
 {
@@ -109,6 +111,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ns = M->n_spheres;
     const int maxlev = M->maxlev;
     const LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
+    static_assert(DEPTH <= DMAX, "path words hold DMAX levels");
     float *const cacheL = lds + L.cache;
     float *const jwL = lds + L.jw;
     float *const baseL = lds + L.base;     // [0:9) Rw0  [9:12) xw0  [12:48) IA0^-1
@@ -117,15 +120,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const lamL = lds + L.lam;
     float *const miscL = lds + L.misc;
     float *const conL = lds + L.con;
-    float *const YdL = lds + L.Yd;
     float *const sdistL = lds + L.sdist;
     float *const scenL = lds + L.scen;       // sphere centres + radius, only with self-collision
     float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, only with self-collision
     int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
     int *const bchL = nsibL + n;                                    // base_children[n]
+    // region AB is time-shared: kinematics exchange (pub) -> child-to-parent ABA exchange (up)
+    // -> contact Jacobians (Jc) -> 6-float exchanges of the final response
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
-    float *const upL = lds + L.AB + PUB * (n + 1);        // UP * n
+    float *const upL = lds + L.AB;                        // UP * n, once pub's poses are consumed
     float *const JcL = lds + L.AB;                        // ndof * NC3 (after the ABA is done)
+    float *const accL = lds + L.acc;                      // 8 * (n+1): accelerations root -> leaves
 
     const bool is_link = lane < n;
     const int S = HG_STATE_SIZE(n);
@@ -419,7 +424,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < 36; k++) baseL[12 + k] = Inv[k];
-                stsv(pubL + PUB * n + 12, a0);
+                stsv(accL + 8 * n, a0);
             }
         }
         wave_sync();
@@ -428,10 +433,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         #pragma unroll 1
         for (int lev = 1; lev <= maxlev; ++lev) {
             if (is_link && mylev == lev) {
-                Sv a = xmotion(E, r, ldsv(pubL + PUB * pidx + 12)) + cor;
+                Sv a = xmotion(E, r, ldsv(accL + 8 * pidx)) + cor;
                 qdd = (u - sdot(U, a)) * Dinv;
                 a = sfma(Sm, qdd, a);
-                stsv(pubL + PUB * lane + 12, a);
+                stsv(accL + 8 * lane, a);
             }
             wave_sync();
         }
@@ -446,7 +451,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ============ 4. constraint rows =======================================================
         // world-frame joint axes and pivots for the contact Jacobians, current velocities
         if (is_link) velL[6 + lane] = qd;
-        if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
+        if (lane == 0) {   // base state is parked in LDS while the rows need the registers
+            st3(velL, bang); st3(velL + 3, bvel);
+            st3(baseL + 9, bpos); baseL[48] = bq[0]; baseL[49] = bq[1]; baseL[50] = bq[2]; baseL[51] = bq[3];
+        }
         wave_sync();      // region AB (pub/up) is dead from here on: Jc may overwrite it
 
         const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
@@ -475,7 +483,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if (body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
                     anc2 = body2 >= 0 ? M->anc_mask[body2] : 0ull;
                 } else {
-                    Jang = cross(pt - bpos, dir);
+                    Jang = cross(pt - ld3(baseL + 9), dir);
                     Jlin = dir;
                 }
             }
@@ -492,7 +500,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 JcL[0 * NC3 + col] = Jang.x; JcL[1 * NC3 + col] = Jang.y; JcL[2 * NC3 + col] = Jang.z;
                 JcL[3 * NC3 + col] = Jlin.x; JcL[4 * NC3 + col] = Jlin.y; JcL[5 * NC3 + col] = Jlin.z;
-                rv += dot(Jang, bang) + dot(Jlin, bvel);
+                rv += dot(Jang, ld3(velL)) + dot(Jlin, ld3(velL + 3));
             }
             if (row_contact) {
                 if (col < MAXC) {
@@ -535,8 +543,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         {
             // (i) walk the own path towards the root, accumulating the zero-acceleration force
             Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
+            float Ys[DEPTH];             // Y of the own-path link at each depth (registers)
 #pragma unroll
-            for (int dd = DMAX; dd >= 1; --dd) {
+            for (int dd = DEPTH; dd >= 1; --dd) {
                 float Y = 0.f;
                 if (dd <= maxlev) {      // wave-uniform
                     const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
@@ -548,8 +557,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         Y = f - sdot(Sl, Z);
                         Z = xforce_up(ldm(pc), ld3(pc + 9), sfma(Ul, Y * pc[18], Z));
                     }
-                    YdL[(dd - 1) * WAVE + lane] = Y;
                 }
+                Ys[dd - 1] = Y;
             }
             if (two_body) {
                 // The impulse of a self-contact row acts on two branches.  By linearity the second
@@ -557,7 +566,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 // the zero-acceleration forces meet at the base.
                 Sv Z2; Z2.a = v3(0, 0, 0); Z2.l = v3(0, 0, 0);
 #pragma unroll
-                for (int dd = DMAX; dd >= 1; --dd) {
+                for (int dd = DEPTH; dd >= 1; --dd) {
                     float Y = 0.f;
                     if (dd <= maxlev) {
                         const int l = (int)((pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
@@ -591,9 +600,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     for (int c = 0; c < NC3; c++) Arow[NMX + c] = fmaf(ub[k], JcL[k * NC3 + c], Arow[NMX + c]);
             }
             // (iii) full descent: joint accelerations of every link for this row's impulse
-            Sv acur = ab, slot[NSLOT];
+            Sv acur = ab, slot[NSL > 0 ? NSL : 1];
 #pragma unroll
-            for (int s = 0; s < NSLOT; s++) slot[s] = ab;
+            for (int s = 0; s < NSL; s++) slot[s] = ab;
             #pragma unroll 1
             for (int i = 0; i < n; ++i) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
@@ -602,12 +611,15 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if (mode == 1) ap = ab;
                 else if (mode >= 2) {
 #pragma unroll
-                    for (int s = 0; s < NSLOT; s++) if (mode == 2 + s) ap = slot[s];
+                    for (int s = 0; s < NSL; s++) if (mode == 2 + s) ap = slot[s];
                 }
                 const float *pc = cacheL + CACHE * i;
                 Sv a = xmotion(ldm(pc), ld3(pc + 9), ap);
                 const int d = (int)((inf >> 8) & 0xffu);
-                float Y = ((myanc >> i) & 1ull) ? YdL[(d - 1) * WAVE + lane] : 0.f;
+                float Y = 0.f;
+#pragma unroll
+                for (int k = 0; k < DEPTH; k++) if (d == k + 1) Y = Ys[k];      // d is wave-uniform
+                Y = ((myanc >> i) & 1ull) ? Y : 0.f;
                 if (two_body && ((myanc2 >> i) & 1ull)) Y += Yd2L[(d - 1) * WAVE + lane];
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
@@ -615,7 +627,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const int sv = (int)((inf >> 16) & 0xffu) - 1;
                 if (sv >= 0) {
 #pragma unroll
-                    for (int s = 0; s < NSLOT; s++) if (sv == s) slot[s] = a;
+                    for (int s = 0; s < NSL; s++) if (sv == s) slot[s] = a;
                 }
                 HG_ROW_SWITCH(i)
                 if (i == lane) diag = qa;
@@ -680,6 +692,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ============ 5. velocities += M^-1 J^T lambda =========================================
         lamL[lane] = lam;
         wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
+        bang = ld3(velL); bvel = ld3(velL + 3); bpos = ld3(baseL + 9);
+        bq[0] = baseL[48]; bq[1] = baseL[49]; bq[2] = baseL[50]; bq[3] = baseL[51];
+        wave_sync();      // F overwrites the velocity vector below
         if (lane < ndof) {
             float f = lane >= 6 ? lamL[lane - 6] : 0.f;
             if (nc > 0) {
