@@ -167,6 +167,13 @@ def main():
         value = total_envs * args.steps / elapsed
         bytes_step = algorithmic_bytes_per_env_step(model, len(sel))
         flops_step = algorithmic_flops_per_env_step(model, cfg, n_contacts=int(round(mean_contacts)))
+        traffic = None   # HBM bytes per launch from committed PMC passes of the same kernel/config, if any
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_c_pmc_nao4096.json")))
+            if args.robot == "nao" and n_envs == 4096:
+                traffic = pm["per_launch"]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         ach_gbs = n_envs * bytes_step / (kernel_ms * 1e-3) / 1e9
         ach_tf = n_envs * flops_step / (kernel_ms * 1e-3) / 1e12
         out = {
@@ -181,7 +188,7 @@ def main():
                        "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters,
                        "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hg_step_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "metric asks for the HBM fraction; the kernel is FP32-VALU bound, see `valu`"},
