@@ -655,15 +655,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
         }
 
+        float mu_v = P.mu;
+        asm volatile("" : "+v"(mu_v));          // keep mu in a VGPR: v_mul may take only one SGPR operand
         #pragma unroll 1
         for (int it = 0; it < P.iters; ++it) {
-            int lane_it = lane;
-            asm volatile("" : "+v"(lane_it));   // keeps the 64 lane==i masks out of SGPRs
+            // lam of lane i alone is overwritten: narrow EXEC to that lane for one v_mov (two scalar
+            // moves + one vector move instead of v_cmp + v_cndmask; the SALU work overlaps other waves).
+            // The kernel runs with all 64 lanes active here, so EXEC is restored to all ones.
             auto row_update = [&](const int i, const float rlo, const float rhi) {
                 const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
                 const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lam), i));
                 z = fmaf(Arow[i], dl, z);
-                lam = (lane_it == i) ? cand : lam;
+                asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
+                             : "+v"(lam) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
             };
             if (it & 1) {
 #pragma unroll
@@ -679,9 +683,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
                     if (c < nc) {
-                        const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lam), NMX + c));
-                        if (tot > 0.f) {
-                            const float lim = P.mu * tot;
+                        const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lam), NMX + c);
+                        if (tot_i > 0) {                      // tot > 0 on the scalar unit (positive float bits)
+                            const float lim = mu_v * __int_as_float(tot_i);
                             row_update(NMX + MAXC + 2 * c, -lim, lim);
                             row_update(NMX + MAXC + 2 * c + 1, -lim, lim);
                         }
