@@ -25,7 +25,8 @@ class BatchedHumanoidEnv(_EnvBase):
     stay on the GPU.
     """
 
-    def __init__(self, model: FlatModel, cfg: SimConfig, n_envs: int = 1, device=None, n_substeps: int = 1):
+    def __init__(self, model: FlatModel, cfg: SimConfig, n_envs: int = 1, device=None, n_substeps: int = 1,
+                 auto_reset: bool = False):
         import torch
         self._torch = torch
         self.model, self.cfg = model, cfg
@@ -33,6 +34,11 @@ class BatchedHumanoidEnv(_EnvBase):
         self.sim = HgSim(model, cfg, self.n_envs, device)
         self.device = self.sim.device
         self.batched = self.n_envs > 1
+        # on-device episode bookkeeping for the batched reward/done pipeline
+        self.auto_reset = bool(auto_reset)
+        z = lambda dt: torch.zeros(self.n_envs, dtype=dt, device=self.device)   # noqa: E731
+        self.episode_return, self.episode_length = z(torch.float32), z(torch.int32)
+        self.last_episode_return, self.last_episode_length = z(torch.float32), z(torch.int32)
 
     # -- helpers -----------------------------------------------------------
     def _actions_tensor(self, actions, width: int):
@@ -53,6 +59,22 @@ class BatchedHumanoidEnv(_EnvBase):
             return x
         v = x[0].tolist()
         return v
+
+    def _finish_step(self, reward, done):
+        """Batched mode: accumulate returns/lengths; envs whose `done` is set are reset in place
+        (masked hg_reset, no host synchronisation) when auto_reset is on."""
+        t = self._torch
+        reward = t.as_tensor(reward, dtype=t.float32, device=self.device).expand(self.n_envs)
+        done = t.as_tensor(done, device=self.device).expand(self.n_envs) != 0
+        self.episode_return += reward
+        self.episode_length += 1
+        self.last_episode_return = t.where(done, self.episode_return, self.last_episode_return)
+        self.last_episode_length = t.where(done, self.episode_length, self.last_episode_length)
+        if self.auto_reset:
+            self.sim.reset(done)
+            self.episode_return = t.where(done, t.zeros_like(self.episode_return), self.episode_return)
+            self.episode_length = t.where(done, t.zeros_like(self.episode_length), self.episode_length)
+        return reward, done
 
     def reset_envs(self, env_mask=None):
         self.sim.reset(env_mask)

@@ -18,12 +18,13 @@ from .base import BatchedHumanoidEnv
 
 
 class DancerEnv(BatchedHumanoidEnv):
-    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, self_collision: bool = False, **cfg_overrides):
+    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, self_collision: bool = False,
+                 n_substeps: int = 1, auto_reset: bool = False, **cfg_overrides):
         model, cfg = load_robot("dancer", urdf_path)
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)
         cfg.enable_self = bool(self_collision)
-        super().__init__(model, cfg, n_envs, device, n_substeps=cfg_overrides.get("n_substeps", 1))
+        super().__init__(model, cfg, n_envs, device, n_substeps=n_substeps, auto_reset=auto_reset)
         # dancer_env.py:66-84 -- maps built from getJointInfo order
         self.joint_names = list(model.joint_names_all)
         self.joint2Index = dict(model.joint2Index)
@@ -51,6 +52,8 @@ class DancerEnv(BatchedHumanoidEnv):
                                  collision=(collision != 0) if self.batched else bool(collision[0].item()),
                                  step_counter=self.step_counter)
         info = {"collision": (collision != 0) if self.batched else bool(collision[0].item())}
+        if self.batched:
+            r, d = self._finish_step(r, d)
         return self._out(obs), r, d, info
 
     # -- what the reference hands to custom_reward ------------------------------

@@ -22,11 +22,12 @@ from .base import BatchedHumanoidEnv
 class _SoftbankEnv(BatchedHumanoidEnv):
     ROBOT = ""
 
-    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, n_substeps: int = 1, **cfg_overrides):
+    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, n_substeps: int = 1,
+                 auto_reset: bool = False, **cfg_overrides):
         model, cfg = load_robot(self.ROBOT, urdf_path)
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)
-        super().__init__(model, cfg, n_envs, device, n_substeps)
+        super().__init__(model, cfg, n_envs, device, n_substeps, auto_reset)
         self.joint_names = [model.dof_names[k] for k in model.act_joint]
         idx = np.asarray(model.act_joint)
         self.lower_limits = model.lower[idx].tolist()

@@ -154,3 +154,26 @@ def test_invalid_arguments_are_rejected():
     _, _, done, _ = sim.step(torch.zeros(4, 18, device="cuda:0"))
     assert done.cpu().tolist() == [0, 0, 1, 0]                                  # env 2 reset in place
     assert bool(torch.isfinite(sim.get_state()).all())
+
+
+def test_batched_custom_reward_and_auto_reset():
+    """custom_reward on device tensors, masked auto-reset without host sync."""
+    import torch
+    env = hg.make("dancer-v0", n_envs=64, auto_reset=True)
+
+    def custom(jointStates, linkStates, collision, step_counter):
+        z = linkStates["body_head"][0][:, 2]                       # COM height of the head link
+        reward = z - 0.3
+        done = torch.arange(64, device=z.device) % 4 == (step_counter % 4)   # a quarter of the envs each step
+        return reward, done
+
+    fresh = env.sim.get_state()[0].clone()
+    for t in range(1, 9):
+        obs, reward, done, info = env.step(torch.zeros(64, 18, device="cuda:0"), custom_reward=custom)
+        assert tuple(obs.shape) == (64, 18) and tuple(reward.shape) == (64,) and done.dtype == torch.bool
+        st = env.sim.get_state()
+        assert bool((st[done] == fresh).all())                     # just-finished envs are back at the reset pose
+        assert bool((env.episode_length[done] == 0).all()) and bool((env.episode_length[~done] > 0).all())
+    assert bool((env.last_episode_length > 0).all()) and bool((env.last_episode_length <= 4).all())
+    assert info["collision"].dtype == torch.bool
+    env.close()

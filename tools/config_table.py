@@ -1,0 +1,41 @@
+"""Times the five BASELINE.json configurations on one GPU (configs 3-5 at their per-GPU size)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from humanoid_gym_amd.robots import load_robot
+from humanoid_gym_amd._capi import HgSim
+from humanoid_gym_amd.workloads import random_actions
+
+def run(name, n_envs, n_substeps=1, reps=30, seed=0, **kw):
+    model, cfg = load_robot(name)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    sim = HgSim(model, cfg, n_envs, "cuda:0")
+    rng = np.random.default_rng(seed)
+    acts = [torch.tensor(random_actions(model, rng, n_envs), device="cuda:0") for _ in range(4)]
+    if name == "dancer":
+        acts = [torch.tensor(rng.uniform(-1, 1, (n_envs, 18)).astype(np.float32), device="cuda:0") for _ in range(4)]
+    for t in range(40):
+        sim.step(acts[(t // 10) % 4], n_substeps=n_substeps)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for t in range(reps):
+        sim.step(acts[(t // 10) % 4], n_substeps=n_substeps)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    _, counts, _ = sim.contact_pairs()
+    fin = bool(torch.isfinite(sim.get_state()).all())
+    print(f"{name:7s} envs={n_envs:6d} substeps={n_substeps} {kw} -> {ms:8.3f} ms/step {n_envs/ms/1e3:8.2f} M env-steps/s "
+          f"contacts={counts.float().mean().item():.1f} finite={fin}", flush=True)
+    sim.close()
+
+if __name__ == "__main__":
+    run("nao", 4096, seed=0)
+    run("pepper", 16384, seed=2)
+    run("romeo", 8192, seed=3)
+    run("romeo", 8192, seed=3, enable_self=False, max_contacts=4)
+    run("dancer", 65536, n_substeps=4, seed=4)
+    run("dancer", 65536, n_substeps=4, seed=4, enable_self=True)
