@@ -64,7 +64,7 @@ def load_softbank_like(name: str, urdf_path: Optional[str] = None) -> FlatModel:
     path = urdf_path or os.path.join(_HERE, f"{name}_like.urdf")
     probe = load_urdf(path, name=name)
     q_init = {k: v for k, v in posture.items() if k in probe.joint2Index}
-    m = load_urdf(path, base_position=(0, 0, 0), q_init=q_init, self_collision=False,
+    m = load_urdf(path, base_position=(0, 0, 0), q_init=q_init, self_collision=True,
                   default_max_force=100000.0, name=name)
     # spawn like qibullet does: upright at the origin, soles 1 mm above the ground plane
     m.base_pos0 = m.base_pos0 + np.array([0.0, 0.0, 0.001 - _lowest_point(m)])
