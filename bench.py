@@ -83,6 +83,11 @@ def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
             "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
 
 
+def _dbg(msg):
+    if os.environ.get("HG_BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +96,11 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--robot", default="nao")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse")
     args = ap.parse_args()
+    if os.environ.get("HG_BENCH_DEBUG"):     # where does a stuck rank sit?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["HG_BENCH_DEBUG"]), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -102,12 +111,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if os.environ.get("HG_BENCH_SINGLE_DEVICE"):     # rehearsal of the N > 1 path on a one-GPU box
+        local_rank = 0
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # torchrun, any N
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    _dbg("process group ready")
 
     model, cfg = load_robot(args.robot)
     n_envs = args.envs_per_gpu
@@ -124,6 +140,7 @@ def main():
     rows_d = torch.tensor(rows, device=dev)
     actions = torch.stack([rows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
     stats = EpisodeStats(sim, reduce_every=16)
+    _dbg("sim and actions ready")
 
     def step(t):
         sim.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1)
@@ -132,7 +149,8 @@ def main():
     for t in range(args.warmup):
         step(t)
     torch.cuda.synchronize()
-    if world > 1:
+    _dbg("warmup done")
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -140,11 +158,12 @@ def main():
         step(t)
     stats.flush()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    _dbg("timed region done")
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -198,7 +217,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,7 +34,9 @@ class EpisodeStats:
         self.total = torch.zeros(self.N, dtype=torch.float32, device=self.device)   # global, as of last reduce
         self.reduce_every = int(reduce_every)
         self.group = group
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # a one-rank group still goes through the collective, so that the path can be rehearsed on one GPU
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.device_collective = self.distributed and (self.device.type != "cuda" or dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self._pending = None
 
@@ -70,6 +72,12 @@ class EpisodeStats:
         self.local.zero_()
         if not self.distributed:
             self.total += snap
+            return
+        if not self.device_collective:
+            # gloo with device tensors (CPU rehearsal of the multi-GPU path only): stage through the host
+            host = snap.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.total += host.to(self.device)
             return
         if self.side is not None:
             self.side.wait_stream(t.cuda.current_stream(self.device))
