@@ -162,11 +162,12 @@ namespace hg {
 struct Variant { int nmx, maxc, depth, nsl, wpe; };
 #define HG_VARIANTS(X) \
     X(0, 18, 12, 6, 0, 4)  /* dancer                                   */ \
-    X(1, 28, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
-    X(2, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
-    X(3, 28, 12, 12, 2, 3) /* pepper (deep chain, branching torso)     */ \
-    X(4, 40, 8, 12, 2, 3)  /* romeo                                    */ \
-    X(5, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
+    X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
+    X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
+    X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
+    X(4, 28, 12, 12, 2, 3) /* pepper (deep chain, branching torso)     */ \
+    X(5, 40, 8, 12, 2, 3)  /* romeo                                    */ \
+    X(6, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));

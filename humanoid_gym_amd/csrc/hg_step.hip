@@ -110,7 +110,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = M->n_spheres;
     const int maxlev = M->maxlev;
-    const LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
+    LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
+    // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
+    // leave them in VGPRs that stay live for the whole kernel)
+    L.AB = __builtin_amdgcn_readfirstlane(L.AB);
+    L.acc = __builtin_amdgcn_readfirstlane(L.acc);
     static_assert(DEPTH <= DMAX, "path words hold DMAX levels");
     float *const cacheL = lds + L.cache;
     float *const jwL = lds + L.jw;
@@ -149,14 +153,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         bchL[lane] = lane < nbc ? M->base_children[lane] : -1;
     }
 
-    // ---- load state ------------------------------------------------------------------
-    float q = 0.f, qd = 0.f, tgt = 0.f;
-    if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; tgt = st[HG_STATE_BASE + 2 * n + lane]; }
-    V3 bpos = ld3(st), bvel = ld3(st + 7), bang = ld3(st + 10);
-    float bq[4] = {st[3], st[4], st[5], st[6]};
+    // The env's state record in HBM is the home of the state between substeps: each substep loads
+    // it and stores it back (L2 hits after the first), so nothing is carried in registers around
+    // the substep loop.
 
     // ---- targets (dancer_env.py:19 / nao_env.py:70) --------------------------------------
     if (P.flags & F_ACTIONS) {
+        float tgt = is_link ? st[HG_STATE_BASE + 2 * n + lane] : 0.f;
         if (is_link) miscL[lane] = tgt;
         wave_sync();
         int mysel = 0;
@@ -167,6 +170,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (is_link) {
             tgt = miscL[lane];
             if (P.flags & F_CLAMP) tgt = fminf(fmaxf(tgt, lk[L_LOWER]), lk[L_UPPER]);
+            st[HG_STATE_BASE + 2 * n + lane] = tgt;     // read back by the same lane below
         }
         wave_sync();
     }
@@ -189,6 +193,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const int pidx = par < 0 ? n : par;
         const int mylev = is_link ? (int)((info_w >> 8) & 0xffu) : 0;
         const int first_child = (int)(kids_w & 0xffu) - 1;
+        float q = 0.f, qd = 0.f;
+        if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
         // ============ 1. kinematics, root -> leaves ============================================
         const V3 ax = ld3(lk + L_AXIS);
         const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace
@@ -202,12 +208,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         Sv v0;
         {
+            const V3 bpos = ld3(st), bvel = ld3(st + 7), bang = ld3(st + 10);
+            const float bq[4] = {st[3], st[4], st[5], st[6]};
             const M3 Rw0 = quat_to_mat(bq[0], bq[1], bq[2], bq[3]);
             v0.a = tmulv(Rw0, bang); v0.l = tmulv(Rw0, bvel);
             if (lane == 0) {
                 float *pb = pubL + PUB * n;
                 stm(pb, Rw0); st3(pb + 9, bpos); stsv(pb + 12, v0);
-                stm(baseL, Rw0); st3(baseL + 9, bpos);
+                stm(baseL, Rw0); st3(baseL + 9, bpos); stsv(baseL + 52, v0);
+                // the base state waits in LDS until the integration (registers are needed elsewhere)
+                baseL[48] = bq[0]; baseL[49] = bq[1]; baseL[50] = bq[2]; baseL[51] = bq[3];
+                st3(baseL + 58, bang); st3(baseL + 61, bvel);
             }
         }
         wave_sync();
@@ -380,7 +391,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 pu[15] = Ip.C.xx; pu[16] = Ip.C.xy; pu[17] = Ip.C.xz; pu[18] = Ip.C.yy; pu[19] = Ip.C.yz; pu[20] = Ip.C.zz;
                 stsv(pu + 21, pp);
                 float *pc = cacheL + CACHE * lane;
-                stm(pc, E); st3(pc + 9, r); stsv(pc + 12, U); pc[18] = Dinv; stsv(pc + 20, Sm);
+                stm(pc, E); st3(pc + 9, r); stsv(pc + 12, U); pc[18] = Dinv; pc[19] = u; stsv(pc + 20, Sm);
+                stsv(accL + 8 * lane, cor);      // read back by the same lane in the downward pass
             }
             wave_sync();
         }
@@ -393,6 +405,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const float bmass = M->base[B_MASS];
             const V3 binertia = ld3(M->base + B_INERTIA);
             const M3 Rw0 = ldm(baseL);
+            const Sv v0 = ldsv(baseL + 52);
             A6[0] = binertia.x; A6[7] = binertia.y; A6[14] = binertia.z; A6[21] = A6[28] = A6[35] = bmass;
             const V3 Iw = v3(binertia.x * v0.a.x, binertia.y * v0.a.y, binertia.z * v0.a.z);
             const V3 g = tmulv(Rw0, v3(P.gx, P.gy, P.gz));
@@ -430,31 +443,40 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         wave_sync();
         // root -> leaves: accelerations
         float qdd = 0.f;
-        #pragma unroll 1
-        for (int lev = 1; lev <= maxlev; ++lev) {
-            if (is_link && mylev == lev) {
-                Sv a = xmotion(E, r, ldsv(accL + 8 * pidx)) + cor;
-                qdd = (u - sdot(U, a)) * Dinv;
-                a = sfma(Sm, qdd, a);
-                stsv(accL + 8 * lane, a);
+        {
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));      // phase-local copies: nothing derived earlier stays live
+            unsigned info_p = info_w;
+            asm volatile("" : "+v"(info_p));
+            const bool is_link = lane_p < n;
+            const int mylev = is_link ? (int)((info_p >> 8) & 0xffu) : 0;
+            const int par = (int)(info_p >> 24) - 1;
+            const int pidx = par < 0 ? n : par;
+            #pragma unroll 1
+            for (int lev = 1; lev <= maxlev; ++lev) {
+                if (mylev == lev) {
+                    const float *pc = cacheL + CACHE * lane_p;
+                    float *pa = accL + 8 * lane_p;
+                    Sv a = xmotion(ldm(pc), ld3(pc + 9), ldsv(accL + 8 * pidx)) + ldsv(pa);
+                    qdd = (pc[19] - sdot(ldsv(pc + 12), a)) * pc[18];
+                    a = sfma(ldsv(pc + 20), qdd, a);
+                    stsv(pa, a);
+                }
+                wave_sync();
             }
-            wave_sync();
         }
         // velocities += dt * unconstrained acceleration
         qd = fmaf(P.dt, qdd, qd);
         {
             const M3 Rw0 = ldm(baseL);
-            bang = bang + mulv(Rw0, a0.a) * P.dt;
-            bvel = bvel + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt;
+            const Sv v0 = ldsv(baseL + 52);
+            const V3 bang = ld3(baseL + 58) + mulv(Rw0, a0.a) * P.dt;
+            const V3 bvel = ld3(baseL + 61) + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt;
+            // ============ 4. constraint rows ===================================================
+            // current velocities for the contact rows
+            if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
         }
-
-        // ============ 4. constraint rows =======================================================
-        // world-frame joint axes and pivots for the contact Jacobians, current velocities
         if (is_link) velL[6 + lane] = qd;
-        if (lane == 0) {   // base state is parked in LDS while the rows need the registers
-            st3(velL, bang); st3(velL + 3, bvel);
-            st3(baseL + 9, bpos); baseL[48] = bq[0]; baseL[49] = bq[1]; baseL[50] = bq[2]; baseL[51] = bq[3];
-        }
         wave_sync();      // region AB (pub/up) is dead from here on: Jc may overwrite it
 
         const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
@@ -513,6 +535,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         if (row_motor) {
+            const float tgt = st[HG_STATE_BASE + 2 * n + lane];
             float tv = fmaf(P.kp * (tgt - q), P.inv_dt, qd) - P.kd * qd;
             const float maxvel = lk[L_MAXVEL];
             tv = fminf(fmaxf(tv, -maxvel), maxvel);
@@ -586,10 +609,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const M3 Rb = ldm(baseL);
             Z.a = Z.a - tmulv(Rb, Jang);
             Z.l = Z.l - tmulv(Rb, Jlin);
-            float Inv[36];
-#pragma unroll
-            for (int k = 0; k < 36; k++) Inv[k] = baseL[12 + k];
-            const Sv ab = neg_mul6(Inv, Z);
+            const Sv ab = neg_mul6(baseL + 12, Z);       // IA0^-1 streamed from LDS
             const V3 uba = mulv(Rb, ab.a), ubl = mulv(Rb, ab.l);
             diag = dot(uba, Jang) + dot(ubl, Jlin);
             if (nc > 0) {
@@ -655,7 +675,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
         }
 
-        float mu_v = P.mu;
+        float mu_s = P.mu;
+        asm volatile("" : "+s"(mu_s));          // opaque: the copy below must not be hoisted out of the substep loop
+        float mu_v = mu_s;
         asm volatile("" : "+v"(mu_v));          // keep mu in a VGPR: v_mul may take only one SGPR operand
         #pragma unroll 1
         for (int it = 0; it < P.iters; ++it) {
@@ -696,8 +718,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ============ 5. velocities += M^-1 J^T lambda =========================================
         lamL[lane] = lam;
         wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
-        bang = ld3(velL); bvel = ld3(velL + 3); bpos = ld3(baseL + 9);
-        bq[0] = baseL[48]; bq[1] = baseL[49]; bq[2] = baseL[50]; bq[3] = baseL[51];
+        V3 bang = ld3(velL), bvel = ld3(velL + 3), bpos = ld3(baseL + 9);
+        float bq[4] = {baseL[48], baseL[49], baseL[50], baseL[51]};
         wave_sync();      // F overwrites the velocity vector below
         if (lane < ndof) {
             float f = lane >= 6 ? lamL[lane - 6] : 0.f;
@@ -737,10 +759,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * bchL[k]);
             Z0.a = Z0.a - tmulv(Rw0, ld3(FL));
             Z0.l = Z0.l - tmulv(Rw0, ld3(FL + 3));
-            float Inv[36];
-#pragma unroll
-            for (int k = 0; k < 36; k++) Inv[k] = baseL[12 + k];
-            const Sv ab = neg_mul6(Inv, Z0);
+            const Sv ab = neg_mul6(baseL + 12, Z0);
             if (lane == 0) stsv(pub6 + 8 * n, ab);
             wave_sync();
             float dq = 0.f;
@@ -760,16 +779,18 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
 
         // ============ 6. integrate positions ==================================================
-        q = fmaf(P.dt, qd, q);
-        bpos = bpos + bvel * P.dt;
+        float dt = P.dt, inv_dt = P.inv_dt;
+        asm volatile("" : "+s"(dt), "+s"(inv_dt));   // opaque: keeps dt-derived constants inside the loop
+        q = fmaf(dt, qd, q);
+        bpos = bpos + bvel * dt;
         {
             float ang = sqrtf(dot(bang, bang));
-            if (ang * P.dt > 0.78539816f) ang = 0.78539816f * P.inv_dt;
+            if (ang * dt > 0.78539816f) ang = 0.78539816f * inv_dt;
             float f;
-            if (ang < 0.001f) f = 0.5f * P.dt - P.dt * P.dt * P.dt * 0.020833333333f * ang * ang;
-            else f = sinf(0.5f * ang * P.dt) / ang;
+            if (ang < 0.001f) f = 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang;
+            else f = sinf(0.5f * ang * dt) / ang;
             const V3 a = bang * f;
-            const float cw = cosf(0.5f * ang * P.dt);
+            const float cw = cosf(0.5f * ang * dt);
             const float x = bq[0], y = bq[1], z = bq[2], s = bq[3];
             float nq[4] = {cw * x + a.x * s + a.y * z - a.z * y,
                            cw * y - a.x * z + a.y * s + a.z * x,
@@ -779,25 +800,40 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
             for (int k = 0; k < 4; k++) bq[k] = nq[k] * inv;
         }
-        wave_sync();
+        // ---- store state ---------------------------------------------------------------------
+        {
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));      // fresh address arithmetic: nothing kept from the loads
+            if (lane_p < n) { st[HG_STATE_BASE + lane_p] = q; st[HG_STATE_BASE + n + lane_p] = qd; }
+        }
+        if (lane == 0) {
+            st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];
+            st3(st + 7, bvel); st3(st + 10, bang);
+        }
+        wave_sync();      // the record is re-read by every lane (next substep, guard below)
     }  // substeps
 
     // ---- non-finite guard: reset the env in place and raise done ---------------------------------
+    float q = 0.f, qd = 0.f;
+    if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
+    V3 bpos = ld3(st);
+    float bq[4] = {st[3], st[4], st[5], st[6]};
     bool bad = !(isfinite(q) && isfinite(qd));
-    bad = bad || !(isfinite(bpos.x + bpos.y + bpos.z + bvel.x + bvel.y + bvel.z + bang.x + bang.y + bang.z + bq[0] + bq[1] + bq[2] + bq[3]));
+    {
+        const V3 bvel = ld3(st + 7), bang = ld3(st + 10);
+        bad = bad || !(isfinite(bpos.x + bpos.y + bpos.z + bvel.x + bvel.y + bvel.z + bang.x + bang.y + bang.z + bq[0] + bq[1] + bq[2] + bq[3]));
+    }
     const bool any_bad = __ballot(bad) != 0ull;
     if (any_bad) {
-        q = is_link ? lk[L_QINIT] : 0.f; qd = 0.f; tgt = q;
-        bpos = ld3(M->base + B_POS0); bvel = v3(0, 0, 0); bang = v3(0, 0, 0);
+        q = is_link ? M->link[lane][L_QINIT] : 0.f; qd = 0.f;
+        bpos = ld3(M->base + B_POS0);
 #pragma unroll
         for (int k = 0; k < 4; k++) bq[k] = M->base[B_QUAT0 + k];
-    }
-
-    // ---- store state -----------------------------------------------------------------------
-    if (is_link) { st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = qd; st[HG_STATE_BASE + 2 * n + lane] = tgt; }
-    if (lane == 0) {
-        st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];
-        st3(st + 7, bvel); st3(st + 10, bang);
+        if (is_link) { st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = 0.f; st[HG_STATE_BASE + 2 * n + lane] = q; }
+        if (lane == 0) {
+            st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];
+            st3(st + 7, v3(0, 0, 0)); st3(st + 10, v3(0, 0, 0));
+        }
     }
 
     // ---- observations and flags (dancer_env.py:32-35,51-52; pepper_env.py:64-68) -----------------
