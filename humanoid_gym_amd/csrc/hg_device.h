@@ -41,6 +41,8 @@ struct DevModel {
     // of one dependent load per tree level / per link:
     uint32_t linkinfo[HG_MAX_LINKS];    // par_mode | level << 8 | (save_slot + 1) << 16 | (parent + 1) << 24
     uint32_t kids[HG_MAX_LINKS];        // (first_child + 1) | (next_sibling + 1) << 8
+    int32_t  lev_start[DMAX + 4];       // links of level l: lev_order[lev_start[l] .. lev_start[l + 1])
+    int8_t   lev_order[HG_MAX_LINKS];   // link indices sorted by level
     uint32_t pathw[HG_MAX_LINKS][4];    // byte d-1 of the 16: path[b][d-1] + 1 (0 = none)
     uint32_t sphere_meta[HG_MAX_SPHERES]; // (link + 1) | flags << 8 | grp_begin << 16 | grp_end << 24
     uint32_t pair_meta[HG_MAX_PAIRS];     // sphere a | sphere b << 8 | (link a + 1) << 16 | (link b + 1) << 24
@@ -94,7 +96,7 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.Yd2 = o;   o += self ? maxlev * WAVE : 0;
     p.sdist = o; o += rup4(ns);
     p.scen = o;  o += self ? 4 * ns : 0;
-    p.tab = o;   o += rup4(2 * n);          // int tables: next_sibling[n], base_children[n]
+    p.tab = o;   o += rup4(4 * n);          // int tables: next_sibling, base_children, first_child, lev_order
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);
     p.total = o;

@@ -206,6 +206,15 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         }
     }
     D->maxlev = maxlev; D->n_base_children = nbc; D->n_slots = nslots;
+    {   // links grouped by level, for the column-parallel leaves -> root sweep
+        int k = 0;
+        for (int l = 0; l < DMAX + 4; l++) D->lev_start[l] = 0;
+        for (int l = 1; l <= maxlev; l++) {
+            D->lev_start[l] = k;
+            for (int i = 0; i < n; i++) if (D->level[i] == l) D->lev_order[k++] = (int8_t)i;
+        }
+        for (int l = maxlev + 1; l < DMAX + 4; l++) D->lev_start[l] = k;
+    }
     for (int i = 0; i < n; i++) {
         D->linkinfo[i] = (uint32_t)(uint8_t)D->par_mode[i] | ((uint32_t)(uint8_t)D->level[i] << 8) |
                          ((uint32_t)(uint8_t)(D->save_slot[i] + 1) << 16) | ((uint32_t)(uint8_t)(D->parent[i] + 1) << 24);

@@ -129,6 +129,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, only with self-collision
     int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
     int *const bchL = nsibL + n;                                    // base_children[n]
+    int *const fchL = nsibL + 2 * n;                                // first_child[n]
+    int *const ordL = nsibL + 3 * n;                                // links sorted by level
     // region AB is time-shared: kinematics exchange (pub) -> child-to-parent ABA exchange (up)
     // -> contact Jacobians (Jc) -> 6-float exchanges of the final response
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
@@ -151,6 +153,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     if (is_link) {
         nsibL[lane] = (int)((kids_w >> 8) & 0xffu) - 1;
         bchL[lane] = lane < nbc ? M->base_children[lane] : -1;
+        fchL[lane] = (int)(kids_w & 0xffu) - 1;
+        ordL[lane] = M->lev_order[lane];
     }
 
     // The env's state record in HBM is the home of the state between substeps: each substep loads
@@ -205,6 +209,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             sincosf(-q, &sq, &cq);
             E = mul(axis_rot(ax, sq, cq), ldm(lk + L_R0));
             r = ld3(lk + L_E) + mulv(E, ld3(lk + L_D));
+        }
+        if (is_link) {     // joint transform and motion subspace of every link, read by all later sweeps
+            float *pc = cacheL + CACHE * lane;
+            stm(pc, E); st3(pc + 9, r); stsv(pc + 20, Sm);
         }
         Sv v0;
         {
@@ -330,71 +338,100 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
 
         // ============ 3. articulated-body algorithm ============================================
-        // bias forces and rigid-body inertias, every link in parallel
-        Sv cor, pA;
-        AI IA;
-        float u = 0.f, Dinv = 0.f;
-        Sv U;
-        {
+        wave_sync();      // pub (poses, velocities) is dead: region AB now holds the child -> parent records
+        // Prelude, lane = link: velocity-product acceleration and bias force.  The link's own `up`
+        // record carries its rigid-body inertia and bias force until the sweep overwrites it.
+        if (is_link) {
             Sv vj; vj.a = ax * qd; vj.l = sl * qd;
             // v already contains vj; v x vj == (v - vj) x vj + 0, use v directly (vj x vj = 0 for the
             // angular part; the linear part keeps both terms)
+            Sv cor, pA;
             cor.a = cross(v.a, vj.a);
             cor.l = cross(v.a, vj.l) + cross(v.l, vj.a);
             const float mass = lk[L_MASS];
             const V3 inertia = ld3(lk + L_INERTIA);
             const V3 Iw = v3(inertia.x * v.a.x, inertia.y * v.a.y, inertia.z * v.a.z);
-            const V3 g = gl;
             const float wn = sqrtf(dot(v.a, v.a)), vn = sqrtf(dot(v.l, v.l));
             pA.a = cross(v.a, Iw) + Iw * (P.ang_damp + P.ang_damp * wn);
-            pA.l = (cross(v.a, v.l) - g + v.l * (P.lin_damp + P.lin_damp * vn)) * mass;
-            IA.A.xx = inertia.x; IA.A.yy = inertia.y; IA.A.zz = inertia.z; IA.A.xy = IA.A.xz = IA.A.yz = 0.f;
-            IA.C.xx = IA.C.yy = IA.C.zz = mass; IA.C.xy = IA.C.xz = IA.C.yz = 0.f;
-#pragma unroll
-            for (int k = 0; k < 9; k++) IA.B.m[k] = 0.f;
+            pA.l = (cross(v.a, v.l) - gl + v.l * (P.lin_damp + P.lin_damp * vn)) * mass;
+            float *pu = upL + UP * lane;
+            st3(pu, inertia); pu[3] = mass; pu[4] = -lk[L_DAMP] * qd;
+            stsv(pu + 21, pA);
+            stsv(accL + 8 * lane, cor);      // read back in the downward pass
         }
-        // leaves -> root
-        #pragma unroll 1
-        for (int lev = maxlev; lev >= 1; --lev) {
-            if (is_link && mylev == lev) {
+        wave_sync();
+        // leaves -> root, 7 lanes per link: lane (g, k) of a link at the current level applies the
+        // link's articulated inertia to one vector -- k < 6: column k of the motion transform to the
+        // parent (giving column k of X^T Ia X), k = 6: the velocity-product acceleration (giving the
+        // bias force handed to the parent).  U, D and the child sums are recomputed by all 7 lanes.
+        {
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));
+            const int g = (lane_p * 37) >> 8;             // lane / 7 for lane < 64
+            const int k = lane_p - 7 * g;
+            #pragma unroll 1
+            for (int lev = maxlev; lev >= 1; --lev) {
+                const int s0 = M->lev_start[lev], cnt = M->lev_start[lev + 1] - s0;
                 #pragma unroll 1
-                for (int c = first_child; c >= 0; c = nsibL[c]) {
-                    const float *pu = upL + UP * c;
-                    IA.A.xx += pu[0]; IA.A.xy += pu[1]; IA.A.xz += pu[2]; IA.A.yy += pu[3]; IA.A.yz += pu[4]; IA.A.zz += pu[5];
+                for (int b0 = 0; b0 < cnt; b0 += 9) {
+                    if (g < 9 && b0 + g < cnt) {
+                        const int link = ordL[s0 + b0 + g];
+                        float *pc = cacheL + CACHE * link;
+                        float *own = upL + UP * link;
+                        AI IA;
+                        IA.A.xx = own[0]; IA.A.yy = own[1]; IA.A.zz = own[2]; IA.A.xy = IA.A.xz = IA.A.yz = 0.f;
+                        IA.C.xx = IA.C.yy = IA.C.zz = own[3]; IA.C.xy = IA.C.xz = IA.C.yz = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 9; k++) IA.B.m[k] += pu[6 + k];
-                    IA.C.xx += pu[15]; IA.C.xy += pu[16]; IA.C.xz += pu[17]; IA.C.yy += pu[18]; IA.C.yz += pu[19]; IA.C.zz += pu[20];
-                    pA = pA + ldsv(pu + 21);
+                        for (int j = 0; j < 9; j++) IA.B.m[j] = 0.f;
+                        const float tau0 = own[4];
+                        Sv pA = ldsv(own + 21);
+                        #pragma unroll 1
+                        for (int c = fchL[link]; c >= 0; c = nsibL[c]) {
+                            const float *pu = upL + UP * c;
+                            IA.A.xx += pu[0]; IA.A.xy += pu[1]; IA.A.xz += pu[2]; IA.A.yy += pu[3]; IA.A.yz += pu[4]; IA.A.zz += pu[5];
+#pragma unroll
+                            for (int j = 0; j < 9; j++) IA.B.m[j] += pu[6 + j];
+                            IA.C.xx += pu[15]; IA.C.xy += pu[16]; IA.C.xz += pu[17]; IA.C.yy += pu[18]; IA.C.yz += pu[19]; IA.C.zz += pu[20];
+                            pA = pA + ldsv(pu + 21);
+                        }
+                        const M3 E = ldm(pc);
+                        const V3 r = ld3(pc + 9);
+                        const Sv Sm = ldsv(pc + 20);
+                        const Sv U = ai_mul(IA, Sm);
+                        const float Dinv = 1.0f / sdot(Sm, U);
+                        const float u = tau0 - sdot(Sm, pA);
+                        // the vector this lane pushes through Ia = IA - U U^T / D
+                        Sv w;
+                        if (k == 6) {
+                            w = ldsv(accL + 8 * link);
+                        } else {
+                            const int m = k < 3 ? k : k - 3;
+                            const V3 col = v3(pc[m], pc[3 + m], pc[6 + m]);          // E e_m (lane-variant m: read from LDS, not registers)
+                            if (k < 3) { w.a = col; w.l = cross(col, r); }
+                            else { w.a = v3(0, 0, 0); w.l = col; }
+                        }
+                        const float t = sdot(U, w) * Dinv;
+                        Sv f = sfma(U, -t, ai_mul(IA, w));
+                        if (k == 6) f = sfma(U, u * Dinv, f + pA);
+                        const Sv o = xforce_up(E, r, f);
+                        // all reads of the own record are issued: overwrite it with the parent-frame data
+                        if (k == 6) {
+                            stsv(own + 21, o);
+                            stsv(pc + 12, U); pc[18] = Dinv; pc[19] = u;
+                        } else {
+                            // column k of X^T Ia X; the packed record keeps rows <= column of A and C, and B by rows
+                            const int m = k < 3 ? k : k - 3;
+                            const V3 sv = k < 3 ? o.a : o.l;
+                            float *blk = own + (k < 3 ? 0 : 15);
+                            blk[m] = sv.x;
+                            if (m >= 1) blk[2 + m] = sv.y;
+                            if (m == 2) blk[5] = sv.z;
+                            if (k < 3) st3(own + 6 + 3 * k, o.l);
+                        }
+                    }
+                    wave_sync();
                 }
-                U = ai_mul(IA, Sm);
-                const float D = sdot(Sm, U);
-                Dinv = 1.0f / D;
-                u = -lk[L_DAMP] * qd - sdot(Sm, pA);
-                AI Ia = IA;
-                sym_rank1_sub(Ia.A, U.a, Dinv);
-                sym_rank1_sub(Ia.C, U.l, Dinv);
-                {
-                    const float ua[3] = {U.a.x * Dinv, U.a.y * Dinv, U.a.z * Dinv};
-                    const float ul[3] = {U.l.x, U.l.y, U.l.z};
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 3; j++) Ia.B.m[3 * i + j] = fmaf(-ua[i], ul[j], Ia.B.m[3 * i + j]);
-                }
-                Sv pa = sfma(U, u * Dinv, pA + ai_mul(Ia, cor));
-                const AI Ip = ai_to_parent(Ia, E, r);
-                const Sv pp = xforce_up(E, r, pa);
-                float *pu = upL + UP * lane;
-                pu[0] = Ip.A.xx; pu[1] = Ip.A.xy; pu[2] = Ip.A.xz; pu[3] = Ip.A.yy; pu[4] = Ip.A.yz; pu[5] = Ip.A.zz;
-#pragma unroll
-                for (int k = 0; k < 9; k++) pu[6 + k] = Ip.B.m[k];
-                pu[15] = Ip.C.xx; pu[16] = Ip.C.xy; pu[17] = Ip.C.xz; pu[18] = Ip.C.yy; pu[19] = Ip.C.yz; pu[20] = Ip.C.zz;
-                stsv(pu + 21, pp);
-                float *pc = cacheL + CACHE * lane;
-                stm(pc, E); st3(pc + 9, r); stsv(pc + 12, U); pc[18] = Dinv; pc[19] = u; stsv(pc + 20, Sm);
-                stsv(accL + 8 * lane, cor);      // read back by the same lane in the downward pass
             }
-            wave_sync();
         }
         // base (every lane computes the same thing; results stay in registers)
         Sv a0;

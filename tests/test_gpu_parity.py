@@ -189,11 +189,28 @@ def test_dancer_self_collision_rows():
             assert worst.max() < 1e-3
         same += int(sum(np.array_equal(p[e], o["pairs"][e]) for e in range(n_envs)))
         saw_self |= bool(((p[..., 1] >= 0) & (p[..., 0] >= 0)).any())
-    # Bounded drift under contact: deeply overlapping foot spheres make the contact normals
-    # ill-conditioned, so single envs may wander; most stay tight and all stay bounded.
-    assert np.median(worst) < 2e-3 and worst.max() < 0.15, worst
+    # Free-running drift under contact is bounded, not tight: deeply overlapping foot spheres make
+    # the contact normals ill-conditioned, so FP32 and FP64 trajectories of single envs separate.
+    assert worst.max() < 0.15, worst
     assert same >= 0.9 * 100 * n_envs
     assert saw_self
     assert set(map(tuple, o["pairs"][0, :o["n_contacts"][0]].tolist())) >= {(11, 17)}
     st = gpu.get_state().cpu().numpy()
     assert np.isfinite(st).all() and np.abs(st[:, :3] - cpu.state[:, :3]).max() < 2e-2
+
+    # The parity statement proper: one step from the SAME state (the GPU is re-seeded with the
+    # oracle's state, rounded to float32 on both sides, before every step), 60 steps in a row.
+    step_err, step_same = 0.0, 0
+    for t in range(60):
+        cpu.state[:] = cpu.state.astype(np.float32)
+        gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+        o = cpu.step(act)
+        gq, gqd, _, _ = gpu.step(ta)
+        pairs, counts, _ = gpu.contact_pairs()
+        eq = [np.array_equal(pairs[e].cpu().numpy(), o["pairs"][e]) for e in range(n_envs)]
+        step_same += sum(eq)
+        for e in range(n_envs):
+            if eq[e]:       # same contact set (a sphere pair exactly at the margin may differ in FP32)
+                step_err = max(step_err, float(np.abs(gq[e].cpu().numpy() - o["q"][e]).max()))
+    assert step_same >= 0.97 * 60 * n_envs, step_same
+    assert step_err < 5e-4, step_err   # FP32 vs FP64 through 150 PGS sweeps over ill-conditioned (overlapping-sphere) rows
