@@ -702,7 +702,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // (w = A lam).  Updating row i by d changes z_j by -A_ji d / A_jj for j != i and leaves
         // z_i unchanged, so the sweep needs one med3, one subtract, one readlane and one fma per
         // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
-        float lam = 0.f, z, lo = 0.f, hi = 0.f;
+        float z, lo = 0.f, hi = 0.f;
         {
             const float dinv = (row_active && diag > 1e-20f) ? 1.0f / diag : 0.f;
             z = target_err * dinv;
@@ -712,21 +712,24 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
         }
 
+        // The impulses live in scalar registers (slam[i] = bits of lam_i): a row update is then
+        //   cand = med3(z, lo, hi);  s_new = readlane(cand, i);  z -= A_i * s_old;  z += A_i * s_new
+        // -- four vector instructions and no write to a single lane.
+        int slam[NROWS];
+#pragma unroll
+        for (int k = 0; k < NROWS; k++) slam[k] = 0;
         float mu_s = P.mu;
         asm volatile("" : "+s"(mu_s));          // opaque: the copy below must not be hoisted out of the substep loop
         float mu_v = mu_s;
         asm volatile("" : "+v"(mu_v));          // keep mu in a VGPR: v_mul may take only one SGPR operand
         #pragma unroll 1
         for (int it = 0; it < P.iters; ++it) {
-            // lam of lane i alone is overwritten: narrow EXEC to that lane for one v_mov (two scalar
-            // moves + one vector move instead of v_cmp + v_cndmask; the SALU work overlaps other waves).
-            // The kernel runs with all 64 lanes active here, so EXEC is restored to all ones.
             auto row_update = [&](const int i, const float rlo, const float rhi) {
                 const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
-                const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lam), i));
-                z = fmaf(Arow[i], dl, z);
-                asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
-                             : "+v"(lam) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
+                const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
+                z = fmaf(-Arow[i], __int_as_float(slam[i]), z);
+                z = fmaf(Arow[i], __int_as_float(s_new), z);
+                slam[i] = s_new;
             };
             if (it & 1) {
 #pragma unroll
@@ -742,7 +745,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
                     if (c < nc) {
-                        const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lam), NMX + c);
+                        const int tot_i = slam[NMX + c];
                         if (tot_i > 0) {                      // tot > 0 on the scalar unit (positive float bits)
                             const float lim = mu_v * __int_as_float(tot_i);
                             row_update(NMX + MAXC + 2 * c, -lim, lim);
@@ -751,6 +754,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     }
             }
         }
+        float lam = 0.f;
+#pragma unroll
+        for (int k = 0; k < NROWS; k++)       // lane k <- lam_k: one v_mov under a one-lane EXEC (all 64 lanes are active here)
+            asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
+                         : "+v"(lam) : "s"(slam[k]), "i"(k < 32 ? (int)(1u << (k & 31)) : 0), "i"(k >= 32 ? (int)(1u << (k & 31)) : 0));
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
         lamL[lane] = lam;

@@ -1,0 +1,37 @@
+"""Prints the worst GPU-vs-oracle joint-angle error of a few scenarios (run by hand on the GPU box;
+not collected by pytest).  usage: python tests/parity_report.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+from _oracle import OracleSim
+from humanoid_gym_amd.robots import load_robot
+from humanoid_gym_amd._capi import HgSim
+
+
+def run(name, n_envs, steps, seed, **kw):
+    model, cfg = load_robot(name)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    gpu, cpu = HgSim(model, cfg, n_envs, "cuda:0"), OracleSim(model, cfg, n_envs)
+    rng = np.random.default_rng(seed)
+    worst = np.zeros(n_envs)
+    ncs = 0
+    for t in range(steps):
+        if t % 24 == 0:
+            act = rng.uniform(-0.5, 0.5, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
+        o = cpu.step(act)
+        gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0]
+        worst = np.maximum(worst, np.abs(gq.cpu().numpy() - o["q"]).max(1))
+        ncs += int(o["n_contacts"].sum())
+    print(f"{name:8s} {kw} steps={steps} contacts/step/env={ncs / steps / n_envs:.1f} "
+          f"worst q err: median {np.median(worst):.2e} max {worst.max():.2e}", flush=True)
+
+
+run("dancer", 8, 240, 1, enable_ground=False, gravity=(0.0, 0.0, 0.0))
+run("dancer", 8, 120, 2)
+run("nao", 8, 240, 3, enable_ground=False)
+run("nao", 8, 240, 4)
+run("pepper", 4, 120, 5)
+run("romeo", 4, 120, 6)
