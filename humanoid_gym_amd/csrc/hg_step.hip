@@ -722,16 +722,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         asm volatile("" : "+s"(mu_s));          // opaque: the copy below must not be hoisted out of the substep loop
         float mu_v = mu_s;
         asm volatile("" : "+v"(mu_v));          // keep mu in a VGPR: v_mul may take only one SGPR operand
-        #pragma unroll 1
-        for (int it = 0; it < P.iters; ++it) {
-            auto row_update = [&](const int i, const float rlo, const float rhi) {
-                const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
-                const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
-                z = fmaf(-Arow[i], __int_as_float(slam[i]), z);
-                z = fmaf(Arow[i], __int_as_float(s_new), z);
-                slam[i] = s_new;
-            };
-            if (it & 1) {
+        auto row_update = [&](const int i, const float rlo, const float rhi) {
+            const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
+            const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
+            z = fmaf(-Arow[i], __int_as_float(slam[i]), z);
+            z = fmaf(Arow[i], __int_as_float(s_new), z);
+            slam[i] = s_new;
+        };
+        // Bullet's row order: motor rows back to front on even sweeps and front to back on odd ones,
+        // then the contact normals, then the friction pairs of contacts that carry a normal impulse.
+        auto sweep = [&](const bool forward) {
+            if (forward) {
 #pragma unroll
                 for (int i = 0; i < NMX; ++i) row_update(i, lo, hi);
             } else {
@@ -753,7 +754,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         }
                     }
             }
-        }
+        };
+        // two sweeps per trip, so that the loop body is straight-line code in the motor rows
+        #pragma unroll 1
+        for (int it = 0; it + 1 < P.iters; it += 2) { sweep(false); sweep(true); }
+        if (P.iters & 1) sweep(false);
         float lam = 0.f;
 #pragma unroll
         for (int k = 0; k < NROWS; k++)       // lane k <- lam_k: one v_mov under a one-lane EXEC (all 64 lanes are active here)
