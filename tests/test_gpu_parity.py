@@ -205,7 +205,7 @@ def test_dancer_self_collision_rows():
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
         o = cpu.step(act)
-        gq, gqd, _, _ = gpu.step(ta)
+        gq, _, _, _ = gpu.step(ta)
         pairs, counts, _ = gpu.contact_pairs()
         eq = [np.array_equal(pairs[e].cpu().numpy(), o["pairs"][e]) for e in range(n_envs)]
         step_same += sum(eq)
@@ -214,3 +214,73 @@ def test_dancer_self_collision_rows():
                 step_err = max(step_err, float(np.abs(gq[e].cpu().numpy() - o["q"][e]).max()))
     assert step_same >= 0.97 * 60 * n_envs, step_same
     assert step_err < 5e-4, step_err   # FP32 vs FP64 through 150 PGS sweeps over ill-conditioned (overlapping-sphere) rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("dancer", 80), ("nao", 120), ("pepper", 80), ("romeo", 80)])
+def test_one_step_parity_from_shared_states(name, steps):
+    """The parity statement that does not depend on how fast FP32 and FP64 trajectories of a falling,
+    contact-rich robot separate: before every step the GPU is re-seeded with the oracle's state (both
+    rounded to float32), random targets change every 12 steps, and ONE step is compared.  Integer
+    outputs (contact count, link pairs, per-link mask, collision flag) must be identical except where
+    a sphere sits within FP32 rounding of the contact margin; joint angles agree to 1e-4 rad."""
+    n_envs = 8
+    model, cfg, gpu, cpu, torch = _mk(name, n_envs)
+    rng = np.random.default_rng(11)
+    lo, hi = np.asarray(model.lower)[model.act_joint], np.asarray(model.upper)[model.act_joint]
+    lo, hi = np.maximum(lo, -1.5), np.minimum(hi, 1.5)
+    same, total, worst_q, worst_qd, saw_contacts = 0, 0, 0.0, 0.0, 0
+    for t in range(steps):
+        if t % 12 == 0:
+            act = rng.uniform(lo, hi, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
+        cpu.state[:] = cpu.state.astype(np.float32)
+        gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+        o = cpu.step(act)
+        gq, _, _, gcol = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))
+        pairs, counts, mask = gpu.contact_pairs()
+        pairs, counts, mask = pairs.cpu().numpy(), counts.cpu().numpy(), mask.cpu().numpy().astype(np.uint64)
+        gq, gqd = gq.cpu().numpy(), gpu.obs_qd.cpu().numpy()
+        saw_contacts += int(o["n_contacts"].sum())
+        for e in range(n_envs):
+            total += 1
+            if counts[e] == o["n_contacts"][e] and np.array_equal(pairs[e], o["pairs"][e]):
+                same += 1
+                assert mask[e] == o["link_mask"][e]
+                assert bool(gcol[e]) == bool(o["collision"][e])
+                worst_q = max(worst_q, float(np.abs(gq[e] - o["q"][e]).max()))
+                worst_qd = max(worst_qd, float(np.abs(gqd[e] - o["qd"][e]).max()))
+    assert saw_contacts > 0
+    assert same >= 0.98 * total, (same, total)
+    assert worst_q < 1e-4, worst_q
+    assert worst_qd < 0.03, worst_qd          # rad/s; q error = dt * qd error, dt = 1/240
+
+
+@pytest.mark.gpu
+def test_edge_sizes_and_contact_slot_saturation():
+    """n_envs = 1 and an odd n_envs; fewer contact slots than touching points (the first max_contacts
+    candidates in sphere order are kept, like the oracle); the largest n_substeps the ABI accepts."""
+    for n_envs in (1, 1001):
+        model, cfg, gpu, cpu, torch = _mk("dancer", n_envs)
+        act = np.zeros((n_envs, model.n_act))
+        for t in range(3):
+            o = cpu.step(act)
+            gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0]
+        assert tuple(gq.shape) == (n_envs, model.n_act)
+        assert np.abs(gq.cpu().numpy() - o["q"]).max() < 1e-5
+        gpu.close()
+    model, cfg, gpu, cpu, torch = _mk("nao", 4, max_contacts=3)
+    act = np.tile(np.asarray(model.q_init)[model.act_joint], (4, 1))
+    ta = torch.tensor(act, dtype=torch.float32, device="cuda:0")
+    for t in range(20):
+        o = cpu.step(act)
+        gq = gpu.step(ta)[0]
+        pairs, counts, _ = gpu.contact_pairs()
+        np.testing.assert_array_equal(counts.cpu().numpy(), o["n_contacts"])
+        np.testing.assert_array_equal(pairs.cpu().numpy(), o["pairs"])
+    assert int(counts.max()) == 3
+    assert np.abs(gq.cpu().numpy() - o["q"]).max() < 1e-4
+    model, cfg, gpu, cpu, torch = _mk("dancer", 2, enable_ground=False)
+    act = np.full((2, model.n_act), 0.2)
+    o = cpu.step(act, n_substeps=1024)
+    gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), n_substeps=1024)[0]
+    assert np.abs(gq.cpu().numpy() - o["q"]).max() < 2e-4
