@@ -784,6 +784,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         {
             float *const up6 = lds + L.AB;             // 8 * n
             float *const pub6 = lds + L.AB + 8 * n;    // 8 * (n + 1)
+            // phase-local topology (fresh from the packed words: nothing from the kinematics stays live)
+            unsigned info_p = info_w, kids_p = kids_w;
+            asm volatile("" : "+v"(info_p), "+v"(kids_p));
+            const int mylev = is_link ? (int)((info_p >> 8) & 0xffu) : 0;
+            const int par = is_link ? (int)(info_p >> 24) - 1 : -1;
+            const int pidx = par < 0 ? n : par;
+            const int first_child = (int)(kids_p & 0xffu) - 1;
             const float Fi = is_link ? FL[6 + lane] : 0.f;
             float Y = 0.f;
             const float *pcm = cacheL + CACHE * li;
