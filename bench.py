@@ -148,6 +148,7 @@ def main():
 
     for t in range(args.warmup):
         step(t)
+    stats.flush()          # one statistics all-reduce outside the timed region (RCCL sets up its channels lazily)
     torch.cuda.synchronize()
     _dbg("warmup done")
     if use_dist:
