@@ -34,15 +34,32 @@ class _SoftbankEnv(BatchedHumanoidEnv):
         self.upper_limits = model.upper[idx].tolist()
         self.init_angles = model.q_init[idx].tolist()
         self.link_names = [model.dof_link_names[k] for k in model.act_joint]     # nao_env.py:40-43
+        # <mimic> joints of the URDF (the fingers of the real NAO / Pepper / Romeo hands) follow the joint
+        # they mimic, as qibullet's setAngles does on the host: target = multiplier * parent + offset.
+        self._mimic = {}
+        for child, (parent, mult, off) in (model.meta.get("mimic") or {}).items():
+            if child in model.dof_names and parent in model.dof_names:
+                self._mimic.setdefault(parent, []).append((model.dof_of(child), float(mult), float(off)))
         n = len(self.joint_names)
         self.observation_space = spaces.Box(np.array([-1] * n, dtype=np.float32), np.array([1] * n, dtype=np.float32))
 
     def _step_sim(self, actions, joints=None):
-        if joints is None:
-            a = self._actions_tensor(actions, len(self.joint_names))
+        names = self.joint_names if joints is None else list(joints)
+        if joints is None and not self._mimic:
+            a = self._actions_tensor(actions, len(names))
             return self.sim.step(a, n_substeps=self.n_substeps)
-        sel = [self.model.dof_of(j) for j in joints]
+        sel = [self.model.dof_of(j) for j in names]
         a = self._actions_tensor(actions, len(sel))
+        if self._mimic:
+            extra, cols = [], []
+            for c, j in enumerate(names):
+                for dof, mult, off in self._mimic.get(j, ()):
+                    if dof not in sel and dof not in extra:
+                        extra.append(dof)
+                        cols.append(a[:, c] * mult + off)
+            if extra:
+                a = self._torch.cat([a, self._torch.stack(cols, dim=1)], dim=1).contiguous()
+                sel = sel + extra
         return self.sim.step(a, joint_sel=sel, n_substeps=self.n_substeps)
 
     def _dict_obs(self):

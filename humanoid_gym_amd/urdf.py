@@ -240,7 +240,10 @@ def load_urdf(path: str,
         ax = el.find("axis")
         lim = el.find("limit")
         dyn = el.find("dynamics")
+        mim = el.find("mimic")
         joints.append(dict(
+            mimic=(mim.get("joint"), float(mim.get("multiplier", 1.0)), float(mim.get("offset", 0.0))) if mim is not None else None,
+            **dict(
             name=el.get("name"), type=el.get("type"),
             parent=el.find("parent").get("link"), child=el.find("child").get("link"),
             xyz=np.array(_floats(o.get("xyz") if o is not None else None, 3)),
@@ -250,7 +253,7 @@ def load_urdf(path: str,
             upper=float(lim.get("upper")) if lim is not None and lim.get("upper") is not None else None,
             effort=float(lim.get("effort")) if lim is not None and lim.get("effort") is not None else None,
             velocity=float(lim.get("velocity")) if lim is not None and lim.get("velocity") is not None else None,
-            damping=float(dyn.get("damping", 0.0)) if dyn is not None else 0.0))
+            damping=float(dyn.get("damping", 0.0)) if dyn is not None else 0.0)))
 
     children = {j["child"] for j in joints}
     roots = [ln for ln in links if ln not in children]
@@ -449,6 +452,10 @@ def load_urdf(path: str,
         pair_a=np.array(pair_a, np.int32), pair_b=np.array(pair_b, np.int32),
         act_joint=np.arange(n, dtype=np.int32),
         meta={"missing_meshes": missing_meshes,
+              # <mimic> joints: child dof name -> [parent joint name, multiplier, offset].  Bullet ignores
+              # the tag; qibullet's setAngles drives such joints from their parent (the hands' fingers).
+              "mimic": {j["name"]: [j["mimic"][0], j["mimic"][1], j["mimic"][2]]
+                        for j in ordered if j["mimic"] is not None and j["type"] != "fixed"},
               "base_position": list(map(float, base_position)),
               "base_orientation": list(map(float, base_orientation))})
     fm.check()

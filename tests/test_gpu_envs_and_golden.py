@@ -207,3 +207,30 @@ def test_full_size_invariants_other_configs(name, n_envs, n_substeps):
     _, counts, _ = sim.contact_pairs()
     assert int(counts.max()) <= cfg.max_contacts
     sim.close()
+
+
+@pytest.mark.gpu
+def test_mimic_joints_follow_their_parent(tmp_path):
+    """with a URDF that has <mimic> finger joints, commanding LHand/RHand also commands
+    the fingers (target = multiplier * hand + offset), through step(actions, joints=)."""
+    import torch
+    import humanoid_gym_amd as hg
+    from _mimic_urdf import write
+    env = hg.make("nao-v0", n_envs=3, urdf_path=write(str(tmp_path / "nao_fingers.urdf")))
+    m = env.model
+    n, lf, rf = m.n_links, m.dof_of("LFinger11"), m.dof_of("RFinger11")
+    tgt = lambda: env.sim.get_state()[:, 13 + 2 * n:].cpu().numpy()
+    obs, *_ = env.step(torch.tensor(np.tile(env.init_angles, (3, 1)), dtype=torch.float32, device="cuda:0"))
+    assert tuple(obs.shape) == (3, 22)           # the 22 NAO joints do not include the hands (nao_env.py:30-31)
+    a = torch.tensor([[0.2, 0.4], [0.5, 0.4], [0.8, 0.4]], device="cuda:0")
+    env.step(a, joints=["LHand", "RHand"])       # h5_control_nao.py:22 drives the hands this way
+    np.testing.assert_allclose(tgt()[:, lf], 0.9 * np.array([0.2, 0.5, 0.8]) + 0.05, atol=1e-6)
+    np.testing.assert_allclose(tgt()[:, rf], 0.9 * 0.4 + 0.05, atol=1e-6)
+    env.step(torch.full((3, 1), 1.0, device="cuda:0"), joints=["RHand"])          # nao_env.py:48
+    np.testing.assert_allclose(tgt()[:, rf], 0.95, atol=1e-6)
+    np.testing.assert_allclose(tgt()[:, lf], 0.9 * np.array([0.2, 0.5, 0.8]) + 0.05, atol=1e-6)   # untouched
+    for _ in range(60):
+        env.step(torch.full((3, 1), 1.0, device="cuda:0"), joints=["RHand"])
+    q = env.sim.get_state()[:, 13:13 + n].cpu().numpy()
+    assert np.abs(q[:, rf] - 0.95).max() < 0.05                                   # the finger got there
+    env.close()

@@ -132,3 +132,16 @@ def test_ragged_and_edge_inputs():
         m.check()
     with pytest.raises(KeyError):
         load_robot("atlas")
+
+
+def test_mimic_tags_are_recorded(tmp_path):
+    """<mimic> joints (the fingers of the real NAO/Pepper hands) become ordinary dofs, as in Bullet, and the
+    loader records (parent, multiplier, offset) so the env can drive them like qibullet's setAngles."""
+    from _mimic_urdf import write
+    from humanoid_gym_amd.robots import NAO_JOINTS
+    m, _ = load_robot("nao", write(str(tmp_path / "nao_fingers.urdf")))
+    assert m.n_links == 28 and [m.dof_names[k] for k in m.act_joint] == NAO_JOINTS
+    assert m.meta["mimic"] == {"LFinger11": ["LHand", 0.9, 0.05], "RFinger11": ["RHand", 0.9, 0.05]}
+    assert m.parent[m.dof_of("LFinger11")] == m.dof_of("LHand")
+    plain, _ = load_robot("nao")
+    assert plain.meta["mimic"] == {}
