@@ -150,3 +150,24 @@ def test_substeps_equal_repeated_steps_and_batch_independence():
     for _ in range(4):
         b.step(act[1:2])
     assert np.abs(a.state[1] - b.state[0]).max() < 1e-12
+
+
+def test_config1_nao_random_control_1000_steps():
+    """BASELINE.json configs[0] / SURVEY 8d "Config 1": NAO, 1 env, 1000 steps of
+    random_control_nao.py:9 (each joint ~ U(lower, upper) every step, default_rng(0)), 1 substep,
+    g = -9.81, 50 solver iterations.  CPU only, the oracle single-threaded; prints its rate (-s)."""
+    import time
+    model, cfg = load_robot("nao")
+    sim = OracleSim(model, cfg, 1)
+    rng = np.random.default_rng(0)
+    lo, hi = np.asarray(model.lower)[model.act_joint], np.asarray(model.upper)[model.act_joint]
+    t0 = time.perf_counter()
+    ncs = 0
+    for t in range(1000):
+        o = sim.step(rng.uniform(lo, hi)[None, :])
+        ncs += int(o["n_contacts"][0])
+    dt = time.perf_counter() - t0
+    print(f"config 1: oracle FP64 single thread {1000 / dt:.0f} env-steps/s, {ncs / 1000:.1f} contacts/step")
+    assert np.isfinite(sim.state).all()
+    assert (np.asarray(o["q"]) >= lo - 1e-6).all() and (np.asarray(o["q"]) <= hi + 0.3).all()
+    assert ncs > 0
