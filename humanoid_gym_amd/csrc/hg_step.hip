@@ -36,60 +36,9 @@ HG_FI void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A[i] = v for a wave-uniform runtime i with compile-time register indices: a switch whose
-// cases each touch one fixed element keeps the row in VGPRs (a helper taking the array by
-// reference made hipcc leave the whole row in scratch memory).
-#define HG_ROW_CASE(I) case I: if constexpr (I < NMX) Arow[I] = qa; break;
-#define HG_ROW_SWITCH(i) switch (i) { \
-        HG_ROW_CASE(0) \
-        HG_ROW_CASE(1) \
-        HG_ROW_CASE(2) \
-        HG_ROW_CASE(3) \
-        HG_ROW_CASE(4) \
-        HG_ROW_CASE(5) \
-        HG_ROW_CASE(6) \
-        HG_ROW_CASE(7) \
-        HG_ROW_CASE(8) \
-        HG_ROW_CASE(9) \
-        HG_ROW_CASE(10) \
-        HG_ROW_CASE(11) \
-        HG_ROW_CASE(12) \
-        HG_ROW_CASE(13) \
-        HG_ROW_CASE(14) \
-        HG_ROW_CASE(15) \
-        HG_ROW_CASE(16) \
-        HG_ROW_CASE(17) \
-        HG_ROW_CASE(18) \
-        HG_ROW_CASE(19) \
-        HG_ROW_CASE(20) \
-        HG_ROW_CASE(21) \
-        HG_ROW_CASE(22) \
-        HG_ROW_CASE(23) \
-        HG_ROW_CASE(24) \
-        HG_ROW_CASE(25) \
-        HG_ROW_CASE(26) \
-        HG_ROW_CASE(27) \
-        HG_ROW_CASE(28) \
-        HG_ROW_CASE(29) \
-        HG_ROW_CASE(30) \
-        HG_ROW_CASE(31) \
-        HG_ROW_CASE(32) \
-        HG_ROW_CASE(33) \
-        HG_ROW_CASE(34) \
-        HG_ROW_CASE(35) \
-        HG_ROW_CASE(36) \
-        HG_ROW_CASE(37) \
-        HG_ROW_CASE(38) \
-        HG_ROW_CASE(39) \
-        HG_ROW_CASE(40) \
-        HG_ROW_CASE(41) \
-        HG_ROW_CASE(42) \
-        HG_ROW_CASE(43) \
-        HG_ROW_CASE(44) \
-        HG_ROW_CASE(45) \
-        HG_ROW_CASE(46) \
-        HG_ROW_CASE(47) \
-        default: break; }
+// register vector of N floats (N <= 16): lets a wave-uniform run-time index address a VGPR directly
+template <int N> struct RegVec { typedef float type __attribute__((ext_vector_type(N))); };
+constexpr int clamp16(int x) { return x < 1 ? 1 : (x > 16 ? 16 : x); }
 
 // NMX: motor-row lanes (>= n dofs), MAXC: contact slots, DEPTH: deepest link level handled,
 // NSL: saved-acceleration slots for branching links, WPE: waves per SIMD the register budget targets.
@@ -596,9 +545,16 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         wave_sync();
 
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
-        float Arow[NROWS];
+        // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
+        // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
+        // instead of a 48-way switch; contact columns: plain registers, compile-time indices only.
+        typedef typename RegVec<clamp16(NMX)>::type VA0;
+        typedef typename RegVec<clamp16(NMX - 16)>::type VA1;
+        typedef typename RegVec<clamp16(NMX - 32)>::type VA2;
+        VA0 AM0 = (VA0)(0.f); VA1 AM1 = (VA1)(0.f); VA2 AM2 = (VA2)(0.f);      // columns 0-15, 16-31, 32-47
+        float AC[NC3 > 0 ? NC3 : 1];
 #pragma unroll
-        for (int k = 0; k < NROWS; k++) Arow[k] = 0.f;
+        for (int k = 0; k < NC3; k++) AC[k] = 0.f;
         float diag = 0.f;
         {
             // (i) walk the own path towards the root, accumulating the zero-acceleration force
@@ -654,7 +610,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int k = 0; k < 6; k++)
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) Arow[NMX + c] = fmaf(ub[k], JcL[k * NC3 + c], Arow[NMX + c]);
+                    for (int c = 0; c < NC3; c++) AC[c] = fmaf(ub[k], JcL[k * NC3 + c], AC[c]);
             }
             // (iii) full descent: joint accelerations of every link for this row's impulse
             Sv acur = ab, slot[NSL > 0 ? NSL : 1];
@@ -686,12 +642,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                     for (int s = 0; s < NSL; s++) if (sv == s) slot[s] = a;
                 }
-                HG_ROW_SWITCH(i)
+                if constexpr (NMX <= 16) AM0[i] = qa;
+                else if constexpr (NMX <= 32) { if (i < 16) AM0[i] = qa; else AM1[i - 16] = qa; }
+                else { if (i < 16) AM0[i] = qa; else if (i < 32) AM1[i - 16] = qa; else AM2[i - 32] = qa; }
                 if (i == lane) diag = qa;
                 if (nc > 0) {
                     const float *jr = JcL + (6 + i) * NC3;
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) Arow[NMX + c] = fmaf(qa, jr[c], Arow[NMX + c]);
+                    for (int c = 0; c < NC3; c++) AC[c] = fmaf(qa, jr[c], AC[c]);
                     if (col >= 0) diag = fmaf(qa, jr[col], diag);
                 }
             }
@@ -707,7 +665,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const float dinv = (row_active && diag > 1e-20f) ? 1.0f / diag : 0.f;
             z = target_err * dinv;
 #pragma unroll
-            for (int k = 0; k < NROWS; k++) Arow[k] = (k == lane) ? 0.f : -Arow[k] * dinv;
+            for (int k = 0; k < NMX; k++) {
+                if (k < 16) AM0[k] = (k == lane) ? 0.f : -AM0[k] * dinv;
+                else if (k < 32) AM1[k - 16] = (k == lane) ? 0.f : -AM1[k - 16] * dinv;
+                else AM2[k - 32] = (k == lane) ? 0.f : -AM2[k - 32] * dinv;
+            }
+#pragma unroll
+            for (int k = 0; k < NC3; k++) AC[k] = (NMX + k == lane) ? 0.f : -AC[k] * dinv;
             if (row_motor) { hi = lk[L_MAXIMP]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
         }
@@ -725,8 +689,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         auto row_update = [&](const int i, const float rlo, const float rhi) {
             const float cand = __builtin_amdgcn_fmed3f(z, rlo, rhi);
             const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
-            z = fmaf(-Arow[i], __int_as_float(slam[i]), z);
-            z = fmaf(Arow[i], __int_as_float(s_new), z);
+            float a_i;          // i is a compile-time constant at every call site (unrolled sweeps)
+            if (i >= NMX) a_i = AC[i >= NMX ? i - NMX : 0];
+            else if (i < 16) a_i = AM0[i < 16 ? i : 0];
+            else if (i < 32) a_i = AM1[i >= 16 && i < 32 && i < NMX ? i - 16 : 0];
+            else a_i = AM2[i >= 32 && i < NMX ? i - 32 : 0];
+            z = fmaf(-a_i, __int_as_float(slam[i]), z);
+            z = fmaf(a_i, __int_as_float(s_new), z);
             slam[i] = s_new;
         };
         // Bullet's row order: motor rows back to front on even sweeps and front to back on odd ones,
