@@ -36,6 +36,13 @@ HG_FI void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Y = Ys[d - 1] if the own-path link at depth d is link i, else 0; one case per depth so that Ys and
+// the packed path words are indexed by compile-time constants only.
+#define HG_Y_CASE(K) case K + 1: if constexpr (K < DEPTH) { \
+        const int pl = (int)((pw[K >> 2] >> (8 * (K & 3))) & 0xffu) - 1; Y = (pl == i) ? Ys[K < DEPTH ? K : 0] : 0.f; } break;
+#define HG_Y_CASES HG_Y_CASE(0) HG_Y_CASE(1) HG_Y_CASE(2) HG_Y_CASE(3) HG_Y_CASE(4) HG_Y_CASE(5) \
+                   HG_Y_CASE(6) HG_Y_CASE(7) HG_Y_CASE(8) HG_Y_CASE(9) HG_Y_CASE(10) HG_Y_CASE(11)
+
 // register vector of N floats (N <= 16): lets a wave-uniform run-time index address a VGPR directly
 template <int N> struct RegVec { typedef float type __attribute__((ext_vector_type(N))); };
 constexpr int clamp16(int x) { return x < 1 ? 1 : (x > 16 ? 16 : x); }
@@ -145,7 +152,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const int par = is_link ? (int)(info_w >> 24) - 1 : -1;
         const int pidx = par < 0 ? n : par;
         const int mylev = is_link ? (int)((info_w >> 8) & 0xffu) : 0;
-        const int first_child = (int)(kids_w & 0xffu) - 1;
         float q = 0.f, qd = 0.f;
         if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
         // ============ 1. kinematics, root -> leaves ============================================
@@ -162,6 +168,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (is_link) {     // joint transform and motion subspace of every link, read by all later sweeps
             float *pc = cacheL + CACHE * lane;
             stm(pc, E); st3(pc + 9, r); stsv(pc + 20, Sm);
+            pc[26] = lk[L_MAXVEL]; pc[27] = lk[L_MAXIMP];      // motor-row limits, read in phase 4
         }
         Sv v0;
         {
@@ -523,7 +530,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (row_motor) {
             const float tgt = st[HG_STATE_BASE + 2 * n + lane];
             float tv = fmaf(P.kp * (tgt - q), P.inv_dt, qd) - P.kd * qd;
-            const float maxvel = lk[L_MAXVEL];
+            const float maxvel = cacheL[CACHE * lane + 26];
             tv = fminf(fmaxf(tv, -maxvel), maxvel);
             target_err = tv - qd;
         }
@@ -620,20 +627,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int i = 0; i < n; ++i) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
                 const int mode = (int)(inf & 0xffu);
-                Sv ap = acur;
-                if (mode == 1) ap = ab;
-                else if (mode >= 2) {
+                const float *pc = cacheL + CACHE * i;
+                // parent acceleration: previous link, base, or a saved branching link -- a scalar branch
+                // per case (mode is wave-uniform), so no register copies are needed to pick one
+                Sv a;
+                if (mode == 0) a = xmotion(ldm(pc), ld3(pc + 9), acur);
+                else if (mode == 1) a = xmotion(ldm(pc), ld3(pc + 9), ab);
+                else {
+                    Sv ap = ab;
 #pragma unroll
                     for (int s = 0; s < NSL; s++) if (mode == 2 + s) ap = slot[s];
+                    a = xmotion(ldm(pc), ld3(pc + 9), ap);
                 }
-                const float *pc = cacheL + CACHE * i;
-                Sv a = xmotion(ldm(pc), ld3(pc + 9), ap);
+                // Y of this link: non-zero only if it is the own-path link of its depth d (wave-uniform)
                 const int d = (int)((inf >> 8) & 0xffu);
                 float Y = 0.f;
-#pragma unroll
-                for (int k = 0; k < DEPTH; k++) if (d == k + 1) Y = Ys[k];      // d is wave-uniform
-                Y = ((myanc >> i) & 1ull) ? Y : 0.f;
-                if (two_body && ((myanc2 >> i) & 1ull)) Y += Yd2L[(d - 1) * WAVE + lane];
+                switch (d) { HG_Y_CASES default: break; }
+                if (two_body) { if ((myanc2 >> i) & 1ull) Y += Yd2L[(d - 1) * WAVE + lane]; }
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
                 acur = a;
@@ -672,7 +682,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
 #pragma unroll
             for (int k = 0; k < NC3; k++) AC[k] = (NMX + k == lane) ? 0.f : -AC[k] * dinv;
-            if (row_motor) { hi = lk[L_MAXIMP]; lo = -hi; }
+            if (row_motor) { hi = cacheL[CACHE * lane + 27]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
         }
 
@@ -754,12 +764,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             float *const up6 = lds + L.AB;             // 8 * n
             float *const pub6 = lds + L.AB + 8 * n;    // 8 * (n + 1)
             // phase-local topology (fresh from the packed words: nothing from the kinematics stays live)
-            unsigned info_p = info_w, kids_p = kids_w;
-            asm volatile("" : "+v"(info_p), "+v"(kids_p));
+            unsigned info_p = info_w;
+            asm volatile("" : "+v"(info_p));
             const int mylev = is_link ? (int)((info_p >> 8) & 0xffu) : 0;
             const int par = is_link ? (int)(info_p >> 24) - 1 : -1;
             const int pidx = par < 0 ? n : par;
-            const int first_child = (int)(kids_p & 0xffu) - 1;
+            const int first_child = is_link ? fchL[lane] : -1;
             const float Fi = is_link ? FL[6 + lane] : 0.f;
             float Y = 0.f;
             const float *pcm = cacheL + CACHE * li;
