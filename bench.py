@@ -11,11 +11,11 @@ Every env replays the same trajectory with a phase offset env_id mod T.
 PD position control + ground contact on, 1 physics substep (1/240 s) per step.
 
 One "step" = one hg_step launch over all envs of this rank (targets -> physics
--> observations) + the on-device episode-statistics accumulation; actions are
-resident in HBM before the timed region.  N > 1: one process per GPU
+-> observations, with the per-env episode-statistics accumulation fused into the
+kernel's output stage); actions are resident in HBM before the timed region.  N > 1: one process per GPU
 (torchrun), envs sharded with no data-path collective; the only collective is
-the RCCL all-reduce of the 8-float episode-statistics vector every 16 steps on
-a side stream.
+hg_stats_flush + the RCCL all-reduce of the 8-float episode-statistics vector
+every 16 steps on a side stream.
 
 Prints ONE JSON line (rank 0).
 """

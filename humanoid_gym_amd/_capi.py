@@ -19,7 +19,7 @@ _lib = None
 
 SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_reset", "hg_step",
            "hg_get_joint_states", "hg_get_link_states", "hg_get_contact_pairs", "hg_get_state",
-           "hg_set_state", "hg_get_layout", "hg_stats_accumulate"]
+           "hg_set_state", "hg_get_layout", "hg_stats_accumulate", "hg_stats_flush"]
 
 
 class HgError(RuntimeError):
@@ -63,6 +63,8 @@ def load_library(path: Optional[str] = None):
     L.hg_get_layout.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     L.hg_stats_accumulate.restype = C.c_int
     L.hg_stats_accumulate.argtypes = [C.c_void_p, fp, u8p, u8p, fp, vp]
+    L.hg_stats_flush.restype = C.c_int
+    L.hg_stats_flush.argtypes = [C.c_void_p, fp, vp]
     if path is None:
         _lib = L
     return L
@@ -189,4 +191,10 @@ class HgSim:
         _check(self.L, self.L.hg_stats_accumulate(self._h, _ptr(self.reward), _ptr(self.done),
                                                   _ptr(self.collision), _ptr(stats), self._stream()),
                "hg_stats_accumulate")
+        return stats
+
+    def stats_flush(self, stats):
+        """Adds the running per-env counters the step kernel keeps (env steps, reward, done, collision)
+        to stats[0:4] and clears them.  stats: float32[8] tensor on this device."""
+        _check(self.L, self.L.hg_stats_flush(self._h, _ptr(stats), self._stream()), "hg_stats_flush")
         return stats

@@ -74,6 +74,7 @@ struct StepOut {
     unsigned long long *link_mask;   // internal, always written
     int32_t *pairs;                  // internal [n_envs][HG_MAX_CONTACTS][2]
     int32_t *counts;                 // internal [n_envs]
+    float   *cum;                    // internal [n_envs][4]: running {steps, reward, done, collision} since the last flush
 };
 
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.

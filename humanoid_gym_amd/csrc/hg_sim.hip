@@ -138,6 +138,24 @@ __global__ void stats_kernel(const float *__restrict__ reward, const uint8_t *__
     }
 }
 
+// stats[0..4) += sum over envs of the running per-env counters, which are cleared
+__global__ void stats_flush_kernel(float *__restrict__ cum, float *__restrict__ stats, int n_envs) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_envs; i += gridDim.x * blockDim.x) {
+        float4 *p = reinterpret_cast<float4 *>(cum) + i;
+        const float4 c = *p;
+        a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+        *p = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(stats + 0, a.x); atomicAdd(stats + 1, a.y); atomicAdd(stats + 2, a.z); atomicAdd(stats + 3, a.w);
+    }
+}
+
 }  // namespace hg
 
 // ---------------------------------------------------------------------------------------
@@ -154,6 +172,7 @@ struct hg_sim {
     float *d_state = nullptr;
     unsigned long long *d_link_mask = nullptr;
     int32_t *d_pairs = nullptr, *d_counts = nullptr;
+    float *d_cum = nullptr;            // [n_envs][4] running episode statistics
 };
 
 namespace hg {
@@ -304,7 +323,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 1; }
+int hg_abi_version(void) { return 2; }
 
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
     if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");
@@ -349,10 +368,12 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     if (e == hipSuccess) e = hipMalloc(&s->d_link_mask, sizeof(unsigned long long) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMalloc(&s->d_cum, sizeof(float) * 4 * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemcpy(s->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMemset(s->d_cum, 0, sizeof(float) * 4 * (size_t)n_envs);
     delete hm;
     if (e != hipSuccess) {
         const std::string msg = std::string("hg_create: ") + hipGetErrorString(e);
@@ -370,7 +391,7 @@ int hg_destroy(hg_sim *s) {
     if (!s) return HG_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_model); (void)hipFree(s->d_state); (void)hipFree(s->d_link_mask);
-    (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts);
+    (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts); (void)hipFree(s->d_cum);
     delete s;
     return HG_OK;
 }
@@ -412,7 +433,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     StepOut O;
     O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;
     O.done = done_dev; O.collision = collision_dev;
-    O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts;
+    O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts; O.cum = s->d_cum;
     HG_HIP(hipSetDevice(s->device));
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
@@ -491,6 +512,16 @@ int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reward_dev, done_dev, collision_dev, stats_dev, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_stats_flush(hg_sim *s, float *stats_dev, void *stream) {
+    if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_flush: null argument");
+    HG_HIP(hipSetDevice(s->device));
+    int blocks = (s->n_envs + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(stats_flush_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_cum, stats_dev, s->n_envs);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }

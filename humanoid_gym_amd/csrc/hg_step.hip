@@ -901,6 +901,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (O.collision) O.collision[env] = (link_mask >> 1) != 0ull ? 1 : 0;
         if (O.reward) O.reward[env] = 0.f;
         if (O.done) O.done[env] = any_bad ? 1 : 0;
+        {   // per-env running episode statistics, reduced and cleared by hg_stats_flush
+            float4 c = *reinterpret_cast<float4 *>(O.cum + 4 * (size_t)env);
+            c.x += 1.f; c.z += any_bad ? 1.f : 0.f; c.w += (link_mask >> 1) != 0ull ? 1.f : 0.f;
+            *reinterpret_cast<float4 *>(O.cum + 4 * (size_t)env) = c;
+        }
         if (O.base_xyyaw) {
             const M3 Rw0 = quat_to_mat(bq[0], bq[1], bq[2], bq[3]);
             const V3 fp = bpos + mulv(Rw0, ld3(M->base + B_FPOS));

@@ -3,11 +3,13 @@
 Envs never read each other's state (dancer_env.py:17-53 touches one body), so
 ranks own disjoint env slices and exchange nothing on the data path.  What a
 trainer wants globally is a handful of sums; each rank keeps an 8-float vector
-on its device ([n_env_steps, sum reward, n_done, n_collision, 0, 0, 0, 0]),
-accumulated by ``hg_stats_accumulate`` right behind the step kernel, and every
-``reduce_every`` steps the vector is all-reduced (RCCL when the backend is
-nccl) on a side stream so that the 64-byte, latency-bound collective never sits
-between two physics launches.
+on its device ([n_env_steps, sum reward, n_done, n_collision, 0, 0, 0, 0]).
+Bound to a sim, the per-step accumulation is fused into the step kernel (running
+per-env counters) and ``hg_stats_flush`` folds them into the vector when a
+reduction is due; ``hg_stats_accumulate`` / explicit tensors remain for callers
+that compute reward and done themselves.  Every ``reduce_every`` steps the
+vector is all-reduced (RCCL when the backend is nccl) on a side stream so that
+the 64-byte, latency-bound collective never sits between two physics launches.
 """
 from __future__ import annotations
 
@@ -24,11 +26,12 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
 class EpisodeStats:
     N = 8
 
-    def __init__(self, sim=None, reduce_every: int = 16, device=None, group=None):
+    def __init__(self, sim=None, reduce_every: int = 16, device=None, group=None, fused: bool = True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.sim = sim
+        self.fused = bool(fused and sim is not None)    # per-step accumulation lives in the step kernel
         self.device = sim.device if sim is not None else torch.device(device or "cpu")
         self.local = torch.zeros(self.N, dtype=torch.float32, device=self.device)
         self.total = torch.zeros(self.N, dtype=torch.float32, device=self.device)   # global, as of last reduce
@@ -59,7 +62,8 @@ class EpisodeStats:
         self.local += add
 
     def update(self, step_index: int):
-        self.accumulate()
+        if not self.fused:
+            self.accumulate()
         if self.reduce_every > 0 and (step_index + 1) % self.reduce_every == 0:
             self.reduce_async()
 
@@ -68,6 +72,8 @@ class EpisodeStats:
         """Snapshot the local sums and all-reduce the snapshot off the compute stream."""
         t = self.torch
         self._wait()
+        if self.fused:
+            self.sim.stats_flush(self.local)
         snap = self.local.clone()
         self.local.zero_()
         if not self.distributed:

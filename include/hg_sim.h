@@ -137,6 +137,17 @@ int hg_get_layout(const hg_sim *sim, int32_t *n_envs, int32_t *n_links, int32_t 
 int hg_stats_accumulate(hg_sim *sim, const float *reward_dev, const uint8_t *done_dev,
                         const uint8_t *collision_dev, float *stats_dev, void *stream);
 
+/*
+ * The same statistics without a reduction launch per step: hg_step keeps, per
+ * env, running counters {env steps, sum of the reward output, done count,
+ * collision count} (fused into the step kernel's output stage; the reference
+ * recomputes such figures in Python from every step's return values,
+ * dancer_env.py:41-53).  hg_stats_flush adds their sums over this sim's envs to
+ * stats_dev[0..4) and clears them, so a caller that reduces every K steps pays
+ * one small launch per K steps.  Counters are not cleared by hg_reset.
+ */
+int hg_stats_flush(hg_sim *sim, float *stats_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,32 @@ def test_mimic_joints_follow_their_parent(tmp_path):
     q = env.sim.get_state()[:, 13:13 + n].cpu().numpy()
     assert np.abs(q[:, rf] - 0.95).max() < 0.05                                   # the finger got there
     env.close()
+
+
+@pytest.mark.gpu
+def test_fused_statistics_equal_per_step_accumulation():
+    """hg_stats_flush (running per-env counters kept by the step kernel) gives the same sums as calling
+    hg_stats_accumulate after every step, is cleared by a flush and is not touched by hg_reset."""
+    model, cfg, sim, torch = _sim("nao", 300)
+    per_step = torch.zeros(8, device="cuda:0")
+    fused = torch.zeros(8, device="cuda:0")
+    bad = sim.get_state(); bad[7, 20] = float("nan"); sim.set_state(bad)      # one env raises done once
+    for t in range(25):
+        sim.step(None)
+        sim.stats_accumulate(per_step)
+        if t == 11:
+            sim.stats_flush(fused)
+            sim.reset()
+    sim.stats_flush(fused)
+    assert per_step[0].item() == 25 * 300 and per_step[2].item() == 1.0
+    assert torch.equal(per_step[:4], fused[:4]), (per_step, fused)
+    again = torch.zeros(8, device="cuda:0")
+    sim.stats_flush(again)
+    assert float(again.abs().sum()) == 0.0
+    from humanoid_gym_amd.stats import EpisodeStats
+    st = EpisodeStats(sim, reduce_every=4)
+    for t in range(10):
+        sim.step(None)
+        st.update(t)
+    tot = st.flush().tolist()
+    assert tot[0] == 10 * 300 and tot[3] == 10 * float((sim.collision != 0).sum().item())
