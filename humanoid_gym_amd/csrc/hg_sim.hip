@@ -184,9 +184,10 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
     X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
     X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
     X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
-    X(4, 28, 12, 12, 2, 3) /* pepper (deep chain, branching torso)     */ \
-    X(5, 40, 8, 12, 2, 3)  /* romeo                                    */ \
-    X(6, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
+    X(4, 20, 8, 12, 2, 4)  /* pepper (deep chain, branching torso)     */ \
+    X(5, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
+    X(6, 40, 8, 12, 2, 3)  /* romeo                                    */ \
+    X(7, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
