@@ -64,6 +64,9 @@ enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8 };
 
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
+    // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
+    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children;
+    int8_t  lev_start[DMAX + 4];
     float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp;
     int8_t  sel[HG_MAX_LINKS];
 };

@@ -165,6 +165,8 @@ struct hg_sim {
     int device = 0;
     int n_envs = 0, n = 0, n_act = 0, state_size = 0;
     int variant = 0;            // index into the (NMX, MAXC) instantiation table
+    int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0;
+    int8_t lev_start[hg::DMAX + 4]{};
     int lds_bytes = 0;
     hg_config cfg{};
     int32_t act_joint[HG_MAX_LINKS]{};
@@ -360,6 +362,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     hg_sim *s = new (std::nothrow) hg_sim;
     if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }
     s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
+    s->n_spheres = hm->n_spheres; s->n_pairs = hm->n_pairs; s->maxlev = hm->maxlev; s->n_base_children = hm->n_base_children;
+    for (int l = 0; l < DMAX + 4; l++) s->lev_start[l] = (int8_t)hm->lev_start[l];
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
     s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, config->enable_self != 0).total;
@@ -425,6 +429,9 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     const hg_config &c = s->cfg;
     P.n_envs = s->n_envs; P.n_substeps = n_substeps; P.iters = c.solver_iters; P.maxc = c.max_contacts;
     P.n_sel = n_sel;
+    P.n = s->n; P.n_spheres = s->n_spheres; P.n_pairs = s->n_pairs; P.n_act = s->n_act; P.maxlev = s->maxlev;
+    P.n_base_children = s->n_base_children;
+    memcpy(P.lev_start, s->lev_start, sizeof P.lev_start);
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0);
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);

@@ -61,11 +61,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     extern __shared__ __align__(16) float lds[];
     const int env = blockIdx.x;
     const int lane_o = threadIdx.x;
-    const int n_o = M->n;
+    const int n_o = P.n;
     const int lane = lane_o, n = n_o;
     const int ndof = 6 + n;
-    const int ns = M->n_spheres;
-    const int maxlev = M->maxlev;
+    const int ns = P.n_spheres;
+    const int maxlev = P.maxlev;
     LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
     // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
     // leave them in VGPRs that stay live for the whole kernel)
@@ -105,7 +105,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     // per-link words are read back by other lanes with v_readlane (no memory access)
     const unsigned info_w = is_link ? M->linkinfo[li] : 0u;
     const unsigned kids_w = is_link ? M->kids[li] : 0u;
-    const int nbc = M->n_base_children;
+    const int nbc = P.n_base_children;
     if (is_link) {
         nsibL[lane] = (int)((kids_w >> 8) & 0xffu) - 1;
         bchL[lane] = lane < nbc ? M->base_children[lane] : -1;
@@ -260,7 +260,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
             if (P.flags & F_SELF) {
                 // sphere pairs of bodies that are not ancestors of one another, in pair order
-                const int np = M->n_pairs;
+                const int np = P.n_pairs;
                 #pragma unroll 1
                 for (int p0 = 0; p0 < np && count < P.maxc; p0 += WAVE) {
                     const int p = p0 + lane;
@@ -327,7 +327,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const int k = lane_p - 7 * g;
             #pragma unroll 1
             for (int lev = maxlev; lev >= 1; --lev) {
-                const int s0 = M->lev_start[lev], cnt = M->lev_start[lev + 1] - s0;
+                const int s0 = P.lev_start[lev], cnt = P.lev_start[lev + 1] - s0;
                 #pragma unroll 1
                 for (int b0 = 0; b0 < cnt; b0 += 9) {
                     if (g < 9 && b0 + g < cnt) {
@@ -875,7 +875,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     // ---- observations and flags (dancer_env.py:32-35,51-52; pepper_env.py:64-68) -----------------
     if (is_link) { miscL[lane] = q; velL[lane] = qd; }
     wave_sync();
-    const int na = M->n_act;
+    const int na = P.n_act;
     if (lane < na) {
         const int j = M->act_joint[lane];
         if (O.obs_q) O.obs_q[(size_t)env * na + lane] = miscL[j];
