@@ -19,7 +19,8 @@ _lib = None
 
 SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_reset", "hg_step",
            "hg_get_joint_states", "hg_get_link_states", "hg_get_contact_pairs", "hg_get_state",
-           "hg_set_state", "hg_get_layout", "hg_stats_accumulate", "hg_stats_flush"]
+           "hg_set_state", "hg_get_layout", "hg_stats_accumulate", "hg_stats_flush",
+           "hg_set_base_velocity"]
 
 
 class HgError(RuntimeError):
@@ -63,6 +64,8 @@ def load_library(path: Optional[str] = None):
     L.hg_get_layout.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     L.hg_stats_accumulate.restype = C.c_int
     L.hg_stats_accumulate.argtypes = [C.c_void_p, fp, u8p, u8p, fp, vp]
+    L.hg_set_base_velocity.restype = C.c_int
+    L.hg_set_base_velocity.argtypes = [C.c_void_p, fp, vp]
     L.hg_stats_flush.restype = C.c_int
     L.hg_stats_flush.argtypes = [C.c_void_p, fp, vp]
     if path is None:
@@ -192,6 +195,16 @@ class HgSim:
                                                   _ptr(self.collision), _ptr(stats), self._stream()),
                "hg_stats_accumulate")
         return stats
+
+    def set_base_velocity(self, cmd):
+        """cmd: [n_envs, 3] (vx, vy in the base heading frame [m/s], yaw rate [rad/s]) or None to release the base."""
+        if cmd is None:
+            _check(self.L, self.L.hg_set_base_velocity(self._h, None, self._stream()), "hg_set_base_velocity")
+            return
+        t = self.torch
+        cmd = cmd.to(device=self.device, dtype=t.float32).contiguous()
+        assert tuple(cmd.shape) == (self.n_envs, 3)
+        _check(self.L, self.L.hg_set_base_velocity(self._h, _ptr(cmd), self._stream()), "hg_set_base_velocity")
 
     def stats_flush(self, stats):
         """Adds the running per-env counters the step kernel keeps (env steps, reward, done, collision)

@@ -60,7 +60,7 @@ struct DevModel {
     float   frame_quat[HG_MAX_LINKS + 1][4];
 };
 
-enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8 };
+enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16 };
 
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
@@ -77,6 +77,7 @@ struct StepOut {
     unsigned long long *link_mask;   // internal, always written
     int32_t *pairs;                  // internal [n_envs][HG_MAX_CONTACTS][2]
     int32_t *counts;                 // internal [n_envs]
+    const float *base_cmd;           // internal [n_envs][3] commanded base (vx, vy, yaw rate), used with F_BASECMD
     float   *cum;                    // internal [n_envs][4]: running {steps, reward, done, collision} since the last flush
 };
 

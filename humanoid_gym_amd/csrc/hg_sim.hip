@@ -175,6 +175,8 @@ struct hg_sim {
     unsigned long long *d_link_mask = nullptr;
     int32_t *d_pairs = nullptr, *d_counts = nullptr;
     float *d_cum = nullptr;            // [n_envs][4] running episode statistics
+    float *d_base_cmd = nullptr;       // [n_envs][3] commanded base velocity, allocated on first use
+    bool base_cmd_on = false;
 };
 
 namespace hg {
@@ -396,7 +398,7 @@ int hg_destroy(hg_sim *s) {
     if (!s) return HG_OK;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_model); (void)hipFree(s->d_state); (void)hipFree(s->d_link_mask);
-    (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts); (void)hipFree(s->d_cum);
+    (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts); (void)hipFree(s->d_cum); (void)hipFree(s->d_base_cmd);
     delete s;
     return HG_OK;
 }
@@ -433,7 +435,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.n_base_children = s->n_base_children;
     memcpy(P.lev_start, s->lev_start, sizeof P.lev_start);
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
-              ((actions_dev && n_sel > 0) ? F_ACTIONS : 0);
+              ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0);
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];
     P.kp = (float)c.kp; P.kd = (float)c.kd; P.erp = (float)c.contact_erp; P.mu = (float)c.friction;
@@ -441,7 +443,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     StepOut O;
     O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;
     O.done = done_dev; O.collision = collision_dev;
-    O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts; O.cum = s->d_cum;
+    O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts; O.cum = s->d_cum; O.base_cmd = s->d_base_cmd;
     HG_HIP(hipSetDevice(s->device));
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
@@ -521,6 +523,22 @@ int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reward_dev, done_dev, collision_dev, stats_dev, s->n_envs);
     HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_set_base_velocity(hg_sim *s, const float *cmd_dev, void *stream) {
+    if (!s) return fail(HG_EINVAL, "hg_set_base_velocity: null handle");
+    HG_HIP(hipSetDevice(s->device));
+    if (!cmd_dev) { s->base_cmd_on = false; return HG_OK; }
+    if (!s->d_base_cmd) {
+        if (hipMalloc(&s->d_base_cmd, sizeof(float) * 3 * (size_t)s->n_envs) != hipSuccess) {
+            s->d_base_cmd = nullptr;
+            return fail(HG_ENOMEM, "hg_set_base_velocity: device allocation failed");
+        }
+    }
+    HG_HIP(hipMemcpyAsync(s->d_base_cmd, cmd_dev, sizeof(float) * 3 * (size_t)s->n_envs, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    s->base_cmd_on = true;
     return HG_OK;
 }
 

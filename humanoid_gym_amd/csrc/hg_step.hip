@@ -172,9 +172,21 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         Sv v0;
         {
-            const V3 bpos = ld3(st), bvel = ld3(st + 7), bang = ld3(st + 10);
+            const V3 bpos = ld3(st);
+            V3 bvel = ld3(st + 7), bang = ld3(st + 10);
             const float bq[4] = {st[3], st[4], st[5], st[6]};
             const M3 Rw0 = quat_to_mat(bq[0], bq[1], bq[2], bq[3]);
+            if (P.flags & F_BASECMD) {
+                // commanded planar base velocity (the three leading action slots of pepper_env.py:53), applied
+                // like qibullet's resetBaseVelocity([vx, vy, 0], [0, 0, theta]) before every physics step
+                const V3 cmd = ld3(O.base_cmd + 3 * (size_t)env);
+                const M3 Rl = mul(Rw0, quat_to_mat(M->base[B_FQUAT], M->base[B_FQUAT + 1], M->base[B_FQUAT + 2], M->base[B_FQUAT + 3]));
+                const float yaw = atan2f(Rl.m[3], Rl.m[0]);
+                float sy, cy;
+                sincosf(yaw, &sy, &cy);
+                bvel = v3(cy * cmd.x - sy * cmd.y, sy * cmd.x + cy * cmd.y, 0.f);
+                bang = v3(0.f, 0.f, cmd.z);
+            }
             v0.a = tmulv(Rw0, bang); v0.l = tmulv(Rw0, bvel);
             if (lane == 0) {
                 float *pb = pubL + PUB * n;

@@ -90,8 +90,15 @@ class NaoEnv(_SoftbankEnv):
 class PepperEnv(_SoftbankEnv):
     ROBOT = "pepper"
 
-    def __init__(self, *a, **kw):
+    # qibullet's limits for PepperVirtual.move [UPSTREAM-RECALL]: 0.55 m/s, 2 rad/s
+    BASE_SCALE = (0.55, 0.55, 2.0)
+
+    def __init__(self, *a, use_base_slots: bool = False, **kw):
+        """use_base_slots=False reproduces the reference (the three leading action slots are ignored and
+        the wheeled base is passive); True wires them to the base: slots in [-1, 1] scale to
+        (vx, vy, yaw rate) = BASE_SCALE * slot (a documented extension)."""
         super().__init__(*a, **kw)
+        self.use_base_slots = bool(use_base_slots)
         assert self.joint_names == PEPPER_JOINTS                       # pepper_env.py:28-39
         # pepper_env.py:53: three extra base slots are declared but never consumed by step()
         self.action_space = spaces.Box(np.array([-1] * 3 + self.lower_limits, dtype=np.float32),
@@ -100,7 +107,12 @@ class PepperEnv(_SoftbankEnv):
     def step(self, actions):                                           # pepper_env.py:56-76
         a = np.asarray(actions.cpu() if hasattr(actions, "cpu") else actions, dtype=np.float32)
         if a.shape[-1] == len(self.joint_names) + 3:
-            a = a[..., 3:]                 # a sampled 15-D action: the base slots are ignored (base is passive)
+            if self.use_base_slots:
+                t = self._torch
+                cmd = t.as_tensor(np.clip(a[..., :3], -1.0, 1.0).reshape(-1, 3) * np.asarray(self.BASE_SCALE, np.float32),
+                                  dtype=t.float32, device=self.device)
+                self.sim.set_base_velocity(cmd.expand(self.n_envs, 3) if cmd.shape[0] == 1 else cmd)
+            a = a[..., 3:]                 # reference behaviour: the base slots are not consumed (pepper_env.py:61)
         obs, reward, done, _ = self._step_sim(a)
         if self.batched:
             return self._dict_obs(), reward, done != 0, {}

@@ -138,6 +138,19 @@ int hg_stats_accumulate(hg_sim *sim, const float *reward_dev, const uint8_t *don
                         const uint8_t *collision_dev, float *stats_dev, void *stream);
 
 /*
+ * Commanded planar base velocity, the three leading action slots that
+ * PepperEnv declares and never consumes (pepper_env.py:53 vs :61; qibullet
+ * exposes the same motion as PepperVirtual.move(x, y, theta)).
+ * cmd_dev [n_envs][3] float32: (vx, vy) in the heading frame of the base link
+ * [m/s], yaw rate [rad/s].  The values are copied; from the next hg_step on the
+ * base velocity is overwritten before every physics substep with
+ * linear (vx, vy, 0) and angular (0, 0, yaw rate), the way qibullet's base
+ * controller calls resetBaseVelocity.  cmd_dev = NULL releases the base (the
+ * reference's behaviour, and the default).
+ */
+int hg_set_base_velocity(hg_sim *sim, const float *cmd_dev, void *stream);
+
+/*
  * The same statistics without a reduction launch per step: hg_step keeps, per
  * env, running counters {env steps, sum of the reward output, done count,
  * collision count} (fused into the step kernel's output stage; the reference

@@ -582,6 +582,26 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
     return 0;
 }
 
+/*
+ * Commanded planar base velocity (the three leading action slots that
+ * pepper_env.py:53 declares): cmd = (vx, vy) in the heading frame of the base LINK frame [m/s] and
+ * the yaw rate [rad/s].  Applied like qibullet's base controller drives Pepper [UPSTREAM-RECALL:
+ * PepperBaseController.move calls resetBaseVelocity([vx_world, vy_world, 0], [0, 0, theta]) every
+ * control cycle]: before every physics step the base velocity is overwritten -- horizontal linear
+ * velocity as commanded, no vertical velocity, yaw rate as commanded, no roll/pitch rate.
+ */
+static void apply_base_cmd(const hg_model *m, double *st, const double *cmd) {
+    double R[9], Rf[9], Rl[9];
+    quat_to_mat(st + 3, R);
+    quat_to_mat(m->frame_quat[0], Rf);
+    m3_mul(R, Rf, Rl);
+    const double yaw = atan2(Rl[3], Rl[0]), cy = cos(yaw), sy = sin(yaw);
+    st[7] = cy * cmd[0] - sy * cmd[1];
+    st[8] = sy * cmd[0] + cy * cmd[1];
+    st[9] = 0.0;
+    st[10] = 0.0; st[11] = 0.0; st[12] = cmd[2];
+}
+
 /* ================================================================== */
 /* exported API                                                        */
 /* ================================================================== */
@@ -607,10 +627,11 @@ void hgo_reset(const hg_model *m, double *state, int n_envs) {
  *   link_mask [n_envs] bit b: body b-1 touched something in the LAST substep
  *   pairs [n_envs][HG_MAX_CONTACTS][2], n_contacts [n_envs]  (nullable)
  */
-int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
-             const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
-             double *obs_q, double *obs_qd, double *base_xyyaw,
-             uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts) {
+int hgo_step_cmd(const hg_model *m, const hg_config *c, int n_envs, double *state,
+                 const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
+                 double *obs_q, double *obs_qd, double *base_xyyaw,
+                 uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts,
+                 const double *base_cmd /* [n_envs][3] or NULL */) {
     const int n = m->n_links, S = HG_STATE_SIZE(n);
     if (joint_sel == NULL) { joint_sel = m->act_joint; n_sel = m->n_act; }
     for (int k = 0; k < n_sel; k++)
@@ -634,8 +655,10 @@ int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
                 if (c->clamp_targets) { if (a < m->lower[j]) a = m->lower[j]; if (a > m->upper[j]) a = m->upper[j]; }
                 tgt[j] = a;
             }
-        for (int s = 0; s < n_substeps; s++)
+        for (int s = 0; s < n_substeps; s++) {
+            if (base_cmd) apply_base_cmd(m, st, base_cmd + 3 * (size_t)e);
             if (physics_step(m, c, st, &info)) err |= 1;
+        }
         for (int k = 0; k < m->n_act; k++) {
             if (obs_q) obs_q[(size_t)e * m->n_act + k] = q[m->act_joint[k]];
             if (obs_qd) obs_qd[(size_t)e * m->n_act + k] = qd[m->act_joint[k]];
@@ -660,6 +683,14 @@ int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
             }
     }
     return err ? -1 : 0;
+}
+
+int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,
+             const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
+             double *obs_q, double *obs_qd, double *base_xyyaw,
+             uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts) {
+    return hgo_step_cmd(m, c, n_envs, state, actions, joint_sel, n_sel, n_substeps, obs_q, obs_qd, base_xyyaw,
+                        collision, link_mask, pairs, n_contacts, NULL);
 }
 
 /* getLinkState (dancer_env.py:27): per body b = 0..n (0 = base)

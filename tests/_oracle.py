@@ -44,6 +44,8 @@ def lib():
                                C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.hgo_step.restype = C.c_int
+        L.hgo_step_cmd.argtypes = L.hgo_step.argtypes + [dp]
+        L.hgo_step_cmd.restype = C.c_int
         L.hgo_link_states.argtypes = [C.POINTER(HgModel), dp, C.c_int, dp, dp, dp, dp]
         L.hgo_link_states.restype = None
         L.hgo_forward_dynamics.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp, dp]
@@ -89,7 +91,7 @@ class OracleSim:
     def targets(self):
         return self.state[:, HG_STATE_BASE + 2 * self.n:]
 
-    def step(self, actions=None, joint_sel=None, n_substeps=1):
+    def step(self, actions=None, joint_sel=None, n_substeps=1, base_cmd=None):
         na = self.model.n_act
         obs_q = np.zeros((self.n_envs, na))
         obs_qd = np.zeros((self.n_envs, na))
@@ -106,12 +108,15 @@ class OracleSim:
         if actions is not None:
             act = np.ascontiguousarray(actions, np.float64).reshape(self.n_envs, -1)
             assert act.shape[1] == (n_sel if joint_sel is not None else na)
-        rc = lib().hgo_step(C.byref(self.cm), C.byref(self.cc), self.n_envs, _dp(self.state), _dp(act),
-                            sel_p, n_sel, n_substeps, _dp(obs_q), _dp(obs_qd), _dp(xyyaw),
-                            col.ctypes.data_as(C.POINTER(C.c_uint8)),
-                            mask.ctypes.data_as(C.POINTER(C.c_uint64)),
-                            pairs.ctypes.data_as(C.POINTER(C.c_int32)),
-                            nc.ctypes.data_as(C.POINTER(C.c_int32)))
+        cmd = None
+        if base_cmd is not None:
+            cmd = np.ascontiguousarray(base_cmd, np.float64).reshape(self.n_envs, 3)
+        rc = lib().hgo_step_cmd(C.byref(self.cm), C.byref(self.cc), self.n_envs, _dp(self.state), _dp(act),
+                                sel_p, n_sel, n_substeps, _dp(obs_q), _dp(obs_qd), _dp(xyyaw),
+                                col.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                mask.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                pairs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                nc.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cmd))
         if rc:
             raise RuntimeError(f"hgo_step failed: {rc}")
         return dict(q=obs_q, qd=obs_qd, base_xyyaw=xyyaw, collision=col, link_mask=mask,

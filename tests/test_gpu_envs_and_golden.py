@@ -263,3 +263,19 @@ def test_fused_statistics_equal_per_step_accumulation():
         st.update(t)
     tot = st.flush().tolist()
     assert tot[0] == 10 * 300 and tot[3] == 10 * float((sim.collision != 0).sum().item())
+
+
+@pytest.mark.gpu
+def test_pepper_base_slots_extension():
+    """pepper-v0 with use_base_slots=True consumes the three leading action slots (pepper_env.py:53);
+    the default ignores them like the reference."""
+    import torch
+    import humanoid_gym_amd as hg
+    for use, lo, hi in ((False, -0.02, 0.02), (True, 0.15, 0.35)):
+        env = hg.make("pepper-v0", n_envs=2, use_base_slots=use)
+        a = np.concatenate([np.tile([0.5, 0.0, 0.0], (2, 1)), np.tile(env.init_angles, (2, 1))], axis=1).astype(np.float32)
+        for _ in range(240):
+            obs, *_ = env.step(a)
+        x = float(obs["position"][0, 0])
+        assert lo < x < hi, (use, x)                  # 1 s at 0.5 * 0.55 m/s = 0.275 m, or nothing
+        env.close()

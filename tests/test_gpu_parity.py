@@ -284,3 +284,32 @@ def test_edge_sizes_and_contact_slot_saturation():
     o = cpu.step(act, n_substeps=1024)
     gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), n_substeps=1024)[0]
     assert np.abs(gq.cpu().numpy() - o["q"]).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_pepper_commanded_base_velocity():
+    """hg_set_base_velocity (the three action slots pepper_env.py:53 declares).  The GPU
+    follows the oracle's restatement step for step, Pepper actually drives along its heading, and
+    releasing the base (NULL) restores the reference's passive base."""
+    n_envs = 4
+    model, cfg, gpu, cpu, torch = _mk("pepper", n_envs)
+    act = np.tile(np.asarray(model.q_init)[model.act_joint], (n_envs, 1))
+    ta = torch.tensor(act, dtype=torch.float32, device="cuda:0")
+    cmd = np.array([[0.3, 0.0, 0.0], [0.0, 0.2, 0.0], [0.0, 0.0, 1.0], [0.25, -0.1, 0.5]])
+    gpu.set_base_velocity(torch.tensor(cmd, dtype=torch.float32))
+    for t in range(120):
+        o = cpu.step(act, base_cmd=cmd)
+        gq = gpu.step(ta)[0]
+        np.testing.assert_allclose(gpu.base_xyyaw.cpu().numpy(), o["base_xyyaw"], atol=2e-3)
+        assert np.abs(gq.cpu().numpy() - o["q"]).max() < 2e-3
+    assert abs(o["base_xyyaw"][0, 0] - 0.3 * 0.5) < 0.03 and abs(o["base_xyyaw"][0, 1]) < 0.02     # 0.5 s at 0.3 m/s
+    assert abs(o["base_xyyaw"][1, 1] - 0.2 * 0.5) < 0.03
+    # turning in place: ground friction at the (non-rolling) stand-in wheels eats part of each step's yaw rate
+    assert 0.3 < o["base_xyyaw"][2, 2] < 0.55 and np.hypot(*o["base_xyyaw"][2, :2]) < 0.02
+    gpu.set_base_velocity(None)
+    before = gpu.base_xyyaw.clone()
+    for t in range(60):
+        o = cpu.step(act)
+        gpu.step(ta)
+    np.testing.assert_allclose(gpu.base_xyyaw.cpu().numpy(), o["base_xyyaw"], atol=5e-3)
+    assert float((gpu.base_xyyaw - before)[0, 0].abs()) < 0.2           # coasts to a stop on friction
