@@ -218,15 +218,35 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         D->anc_mask[i] = (1ull << i) | (p >= 0 ? D->anc_mask[p] : 0ull);
         for (int d = 0; d < DMAX; d++) D->path[i][d] = -1;
         for (int a = i; a >= 0; a = m->parent[a]) D->path[i][D->level[a] - 1] = (int8_t)a;
-        // how the full-descent walk finds the parent's acceleration
-        if (p < 0) D->par_mode[i] = 1;
-        else if (p == i - 1) D->par_mode[i] = 0;
-        else {
-            if (D->save_slot[p] < 0) {
-                if (nslots >= NSLOT) { *why = "too many branching links"; return HG_EUNSUPPORTED; }
-                D->save_slot[p] = (int8_t)nslots++;
+    }
+    // How the full-descent walk (links in index order) finds the parent's acceleration: the previous
+    // link (mode 0), the base (mode 1), or a saved copy (mode 2 + slot).  A link with a child
+    // that does not directly follow it keeps its acceleration in a slot from its own visit until its last child has been
+    // visited; slots are recycled, so NSLOT bounds the NESTING of branching links (torso -> hand ->
+    // fingers is 2), not their number.
+    {
+        int owner[NSLOT], last_kid[HG_MAX_LINKS];
+        for (int k = 0; k < NSLOT; k++) owner[k] = -1;
+        for (int i = 0; i < n; i++) last_kid[i] = last_child[i];
+        for (int i = 0; i < n; i++) {
+            const int p = m->parent[i];
+            for (int k = 0; k < NSLOT; k++)
+                if (owner[k] >= 0 && last_kid[owner[k]] < i) owner[k] = -1;
+            if (p < 0) D->par_mode[i] = 1;
+            else if (p == i - 1) D->par_mode[i] = 0;
+            else {
+                if (D->save_slot[p] < 0) { *why = "internal: branching link without a slot"; return HG_EINVAL; }
+                D->par_mode[i] = (int8_t)(2 + D->save_slot[p]);
             }
-            D->par_mode[i] = (int8_t)(2 + D->save_slot[p]);
+            bool needs = false;        // some child does not follow its parent directly in index order
+            for (int c = i + 2; c < n; c++) needs = needs || m->parent[c] == i;
+            if (needs) {
+                int k = 0;
+                while (k < NSLOT && owner[k] >= 0) k++;
+                if (k == NSLOT) { *why = "branching links nested deeper than 2"; return HG_EUNSUPPORTED; }
+                owner[k] = i; D->save_slot[i] = (int8_t)k;
+                if (k + 1 > nslots) nslots = k + 1;
+            }
         }
     }
     D->maxlev = maxlev; D->n_base_children = nbc; D->n_slots = nslots;

@@ -313,3 +313,57 @@ def test_pepper_commanded_base_velocity():
         gpu.step(ta)
     np.testing.assert_allclose(gpu.base_xyyaw.cpu().numpy(), o["base_xyyaw"], atol=5e-3)
     assert float((gpu.base_xyyaw - before)[0, 0].abs()) < 0.2           # coasts to a stop on friction
+
+
+_TREES = [
+    # (generator arguments, config overrides): chosen so that every kernel variant of hg_sim.hip runs
+    (dict(n_links=46, max_depth=12, n_chains=4, branch_at=((0, 3), (0, 5)), seed=1), dict(max_contacts=6)),   # 46 rows, nested forks
+    (dict(n_links=38, max_depth=10, n_chains=5, branch_at=((1, 2),), seed=2), dict(max_contacts=8)),          # 33..40 rows
+    (dict(n_links=12, max_depth=12, n_chains=1, seed=3), dict(max_contacts=8)),                               # depth-12 chain
+    (dict(n_links=28, max_depth=6, n_chains=5, seed=4), dict(max_contacts=12)),                               # 28 rows, 12 contacts
+    (dict(n_links=27, max_depth=7, n_chains=3, branch_at=((0, 2), (1, 2), (2, 2)), seed=5), dict(max_contacts=8)),  # 3 forks in a row: slot reuse
+    (dict(n_links=20, max_depth=6, n_chains=4, seed=6), dict(max_contacts=8, enable_self=True)),               # self-collision pairs
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(_TREES)))
+def test_random_trees_one_step_parity(case, tmp_path):
+    """Random articulated trees (tests/_random_urdf.py) through URDF loader, oracle and GPU: one step
+    from a shared state, every step of a 0.6 s fall onto the ground with random motor targets."""
+    import torch
+    from _random_urdf import write_random_tree
+    from humanoid_gym_amd.urdf import load_urdf
+    from humanoid_gym_amd.model import SimConfig
+    from humanoid_gym_amd._capi import HgSim
+    gen, over = _TREES[case]
+    path, made = write_random_tree(str(tmp_path / "tree.urdf"), **gen)
+    model = load_urdf(path, base_position=(0, 0, 0.25), self_collision=bool(over.get("enable_self")), name="tree")
+    assert model.n_links == gen["n_links"]
+    cfg = SimConfig()
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    n_envs = 6
+    gpu, cpu = HgSim(model, cfg, n_envs, "cuda:0"), OracleSim(model, cfg, n_envs)
+    rng = np.random.default_rng(100 + case)
+    cpu.state[:, 7:13] = rng.uniform(-0.5, 0.5, (n_envs, 6))            # tumbling start, different per env
+    same, total, worst_q, contacts = 0, 0, 0.0, 0
+    for t in range(150):
+        if t % 15 == 0:
+            act = rng.uniform(-1.0, 1.0, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
+        cpu.state[:] = cpu.state.astype(np.float32)
+        gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+        o = cpu.step(act)
+        gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
+        pairs, counts, mask = gpu.contact_pairs()
+        pairs, counts = pairs.cpu().numpy(), counts.cpu().numpy()
+        contacts += int(o["n_contacts"].sum())
+        for e in range(n_envs):
+            total += 1
+            if counts[e] == o["n_contacts"][e] and np.array_equal(pairs[e], o["pairs"][e]):
+                same += 1
+                worst_q = max(worst_q, float(np.abs(gq[e] - o["q"][e]).max()))
+    assert contacts > 0
+    assert same >= 0.97 * total, (same, total)
+    assert worst_q < 2e-4, worst_q
+    assert np.isfinite(cpu.state).all()
