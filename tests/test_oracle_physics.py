@@ -36,9 +36,17 @@ def _mass_matrix(sim, model, gravity):
     return M, Qg
 
 
-@pytest.mark.parametrize("name", ["dancer", "nao", "pepper", "romeo"])
-def test_aba_matches_mass_matrix(name):
-    model, cfg = load_robot(name)
+@pytest.mark.parametrize("name", ["dancer", "nao", "pepper", "romeo", "tree46", "tree27"])
+def test_aba_matches_mass_matrix(name, tmp_path):
+    if name.startswith("tree"):        # random trees (nested forks, depth 9; three forks in a row)
+        from _random_urdf import write_random_tree
+        from humanoid_gym_amd.urdf import load_urdf
+        gen = {"tree46": dict(n_links=46, max_depth=12, n_chains=4, branch_at=((0, 3), (0, 5)), seed=1),
+               "tree27": dict(n_links=27, max_depth=7, n_chains=3, branch_at=((0, 2), (1, 2), (2, 2)), seed=5)}[name]
+        path, _ = write_random_tree(str(tmp_path / "tree.urdf"), **gen)
+        model, cfg = load_urdf(path, base_position=(0, 0, 0.25), name="tree"), SimConfig()
+    else:
+        model, cfg = load_robot(name)
     cfg.lin_damping = cfg.ang_damping = 0.0
     cfg.enable_ground = False
     sim = OracleSim(model, cfg, 1)
