@@ -492,10 +492,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         int body2 = -3;                                  // second body of a self-contact row, else < -1
         float target_err = 0.f;                          // desired change of J.v
         V3 Jang = v3(0, 0, 0), Jlin = v3(0, 0, 0);
+        // ancestor mask and packed path (ancestor-or-self per depth) of the bodies a contact row acts on
+        unsigned long long myanc = 0ull, myanc2 = 0ull;
+        unsigned pw[3] = {0u, 0u, 0u}, pw2[3] = {0u, 0u, 0u};
+        unsigned long long rowmask = 0ull;       // links with a non-zero row in Jc (wave-uniform)
         if (nc > 0) {
             V3 pt = v3(0, 0, 0), dir = v3(0, 0, 0);
             float dist = 0.f;
-            unsigned long long anc = 0, anc2 = 0;
             if (row_contact) {
                 const float *co = conL + CON * cidx;
                 body = __float_as_int(co[0]);
@@ -506,25 +509,64 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 V3 t1, t2;
                 plane_space(nrm, t1, t2);
                 dir = col < MAXC ? nrm : (((col - MAXC) & 1) ? t2 : t1);
-                anc = body >= 0 ? M->anc_mask[body] : 0ull;
+                if (body >= 0) {
+                    myanc = M->anc_mask[body];
+                    const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
+                    pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
+                }
                 if (body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
-                    anc2 = body2 >= 0 ? M->anc_mask[body2] : 0ull;
+                    if (body2 >= 0) {
+                        myanc2 = M->anc_mask[body2];
+                        const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body2]);
+                        pw2[0] = t.x; pw2[1] = t.y; pw2[2] = t.z;
+                    }
                 } else {
                     Jang = cross(pt - ld3(baseL + 9), dir);
                     Jlin = dir;
                 }
             }
-            float rv = 0.f;
-            if (col >= 0) {
+            // joint part of Jc: zero everywhere ...
+            {
+                float4 *z4 = reinterpret_cast<float4 *>(JcL + 6 * NC3);
+                float zero = 0.f;
+                asm volatile("" : "+v"(zero));       // materialised here: a hoisted zero quad would be spilled
                 #pragma unroll 1
-                for (int i = 0; i < n; ++i) {
-                    const float *pj = jwL + 8 * i;
-                    float j = 0.f;
-                    const int sg = (int)((anc >> i) & 1ull) - (int)((anc2 >> i) & 1ull);
-                    if (sg != 0) j = (float)sg * dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
-                    JcL[(6 + i) * NC3 + col] = j;
-                    rv = fmaf(j, velL[6 + i], rv);
+                for (int k = lane; k < (n * NC3) / 4; k += WAVE) z4[k] = make_float4(zero, zero, zero, zero);
+            }
+            wave_sync();
+            // ... except on the path(s) from the contact bodies to the base: at most DEPTH entries per column
+            float rv = 0.f;
+            const bool two = __ballot(myanc2 != 0ull) != 0ull;
+            if (row_contact) {
+#pragma unroll
+                for (int dd = 1; dd <= DEPTH; ++dd) {
+                    if (dd <= maxlev) {      // wave-uniform
+                        const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        if (l >= 0) {
+                            const float *pj = jwL + 8 * l;
+                            const float j = dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                            JcL[(6 + l) * NC3 + col] = j;
+                            rv = fmaf(j, velL[6 + l], rv);
+                        }
+                    }
                 }
+                if (two) {
+                    // second body: opposite sign; entries of common ancestors cancel exactly (same axis, pivot, point)
+#pragma unroll
+                    for (int dd = 1; dd <= DEPTH; ++dd) {
+                        if (dd <= maxlev) {
+                            const int l = (int)((pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                            if (l >= 0) {
+                                const float *pj = jwL + 8 * l;
+                                const float j = -dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                                JcL[(6 + l) * NC3 + col] += j;
+                                rv = fmaf(j, velL[6 + l], rv);
+                            }
+                        }
+                    }
+                }
+            }
+            if (col >= 0) {
                 JcL[0 * NC3 + col] = Jang.x; JcL[1 * NC3 + col] = Jang.y; JcL[2 * NC3 + col] = Jang.z;
                 JcL[3 * NC3 + col] = Jlin.x; JcL[4 * NC3 + col] = Jlin.y; JcL[5 * NC3 + col] = Jlin.z;
                 rv += dot(Jang, ld3(velL)) + dot(Jlin, ld3(velL + 3));
@@ -538,6 +580,20 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     target_err = -rv;
                 }
             }
+            // which links have a non-zero row in Jc: OR of the ancestor masks of the contact bodies, read
+            // from the normal rows (lane NMX + c) on the scalar unit
+            {
+                const unsigned long long m = myanc | myanc2;
+                const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
+                unsigned rlo = 0u, rhi = 0u;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) {
+                        rlo |= (unsigned)__builtin_amdgcn_readlane(mlo, NMX + c);
+                        if constexpr (NMX > 32) rhi |= (unsigned)__builtin_amdgcn_readlane(mhi, NMX + c);
+                    }
+                rowmask = ((unsigned long long)rhi << 32) | rlo;
+            }
         }
         if (row_motor) {
             const float tgt = st[HG_STATE_BASE + 2 * n + lane];
@@ -547,18 +603,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             target_err = tv - qd;
         }
         const bool row_active = row_motor || row_contact;
-        // one load each: ancestor mask and packed path (ancestor-or-self per depth) of this row's body
-        unsigned long long myanc = 0ull, myanc2 = 0ull;
-        unsigned pw[3] = {0u, 0u, 0u}, pw2[3] = {0u, 0u, 0u};
-        if (row_active && body >= 0) {
-            myanc = M->anc_mask[body];
-            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
+        if (row_motor) {     // motor rows act on their own link
+            myanc = M->anc_mask[lane];
+            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[lane]);
             pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
-        }
-        if (row_contact && body2 >= 0) {
-            myanc2 = M->anc_mask[body2];
-            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body2]);
-            pw2[0] = t.x; pw2[1] = t.y; pw2[2] = t.z;
         }
         const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
         wave_sync();
@@ -668,7 +716,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 else if constexpr (NMX <= 32) { if (i < 16) AM0[i] = qa; else AM1[i - 16] = qa; }
                 else { if (i < 16) AM0[i] = qa; else if (i < 32) AM1[i - 16] = qa; else AM2[i - 32] = qa; }
                 if (i == lane) diag = qa;
-                if (nc > 0) {
+                if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
 #pragma unroll
                     for (int c = 0; c < NC3; c++) AC[c] = fmaf(qa, jr[c], AC[c]);
