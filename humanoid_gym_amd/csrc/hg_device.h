@@ -67,7 +67,7 @@ struct StepParams {
     // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
     int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children;
     int8_t  lev_start[DMAX + 4];
-    float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp;
+    float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp, vmax;
     int8_t  sel[HG_MAX_LINKS];
 };
 

@@ -18,6 +18,10 @@ HG_FI float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); 
 HG_FI V3 cross(V3 a, V3 b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// clamp to [-m, m] that lets NaN through (v_med3 / fmin / fmax would turn it into a bound and hide it from the
+// non-finite guard at the end of the step)
+HG_FI float clampv(float x, float m) { x = x > m ? m : x; return x < -m ? -m : x; }
+HG_FI V3 clamp3(V3 a, float m) { return v3(clampv(a.x, m), clampv(a.y, m), clampv(a.z, m)); }
 HG_FI V3 fma3(V3 a, float s, V3 c) { return v3(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)); }
 
 struct M3 { float m[9]; };  // row-major

@@ -460,6 +460,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];
     P.kp = (float)c.kp; P.kd = (float)c.kd; P.erp = (float)c.contact_erp; P.mu = (float)c.friction;
     P.margin = (float)c.contact_margin; P.lin_damp = (float)c.lin_damping; P.ang_damp = (float)c.ang_damping;
+    P.vmax = c.max_coord_velocity > 0 ? (float)c.max_coord_velocity : 3.0e38f;
     StepOut O;
     O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;
     O.done = done_dev; O.collision = collision_dev;

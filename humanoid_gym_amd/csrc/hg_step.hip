@@ -471,12 +471,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         // velocities += dt * unconstrained acceleration
-        qd = fmaf(P.dt, qdd, qd);
+        // (every velocity coordinate is clamped to +-vmax after each update, as btMultiBody does)
+        qd = clampv(fmaf(P.dt, qdd, qd), P.vmax);
         {
             const M3 Rw0 = ldm(baseL);
             const Sv v0 = ldsv(baseL + 52);
-            const V3 bang = ld3(baseL + 58) + mulv(Rw0, a0.a) * P.dt;
-            const V3 bvel = ld3(baseL + 61) + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt;
+            const V3 bang = clamp3(ld3(baseL + 58) + mulv(Rw0, a0.a) * P.dt, P.vmax);
+            const V3 bvel = clamp3(ld3(baseL + 61) + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt, P.vmax);
             // ============ 4. constraint rows ===================================================
             // current velocities for the contact rows
             if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
@@ -869,9 +870,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 wave_sync();
             }
-            qd += dq;
-            bang = bang + mulv(Rw0, ab.a);
-            bvel = bvel + mulv(Rw0, ab.l);
+            qd = clampv(qd + dq, P.vmax);
+            bang = clamp3(bang + mulv(Rw0, ab.a), P.vmax);
+            bvel = clamp3(bvel + mulv(Rw0, ab.l), P.vmax);
         }
 
         // ============ 6. integrate positions ==================================================

@@ -78,6 +78,7 @@ class HgConfig(C.Structure):
         ("contact_margin", C.c_double),
         ("lin_damping", C.c_double),
         ("ang_damping", C.c_double),
+        ("max_coord_velocity", C.c_double),
         ("solver_iters", C.c_int32),
         ("max_contacts", C.c_int32),
         ("enable_ground", C.c_int32),
@@ -102,6 +103,7 @@ class SimConfig:
     contact_margin: float = 0.02
     lin_damping: float = 0.04
     ang_damping: float = 0.04
+    max_coord_velocity: float = 100.0    # btMultiBody m_maxCoordinateVelocity [UPSTREAM-RECALL]
     solver_iters: int = 50
     max_contacts: int = 8
     enable_ground: bool = True
@@ -117,6 +119,7 @@ class SimConfig:
         c.friction = self.friction
         c.contact_margin = self.contact_margin
         c.lin_damping, c.ang_damping = self.lin_damping, self.ang_damping
+        c.max_coord_velocity = self.max_coord_velocity
         c.solver_iters = int(self.solver_iters)
         c.max_contacts = int(self.max_contacts)
         c.enable_ground = int(self.enable_ground)

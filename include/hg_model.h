@@ -91,6 +91,8 @@ typedef struct hg_config {
     double  contact_margin;    /* manifold distance threshold, 0.02                   */
     double  lin_damping;       /* Bullet multibody default 0.04                       */
     double  ang_damping;       /* Bullet multibody default 0.04                       */
+    double  max_coord_velocity;/* btMultiBody m_maxCoordinateVelocity, 100: every velocity coordinate
+                                  is clamped to +-this after each velocity update; <= 0: off */
     int32_t solver_iters;      /* 150 (dancer_env.py:64) / 50                         */
     int32_t max_contacts;      /* <= HG_MAX_CONTACTS                                  */
     int32_t enable_ground;     /* plane z = 0                                         */

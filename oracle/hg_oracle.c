@@ -463,6 +463,18 @@ typedef struct {
     double lambda_n[HG_MAX_CONTACTS];
 } step_info_t;
 
+/* btMultiBody::applyDeltaVeeMultiDof clamps every velocity coordinate to +-m_maxCoordinateVelocity
+ * (100 by default) each time velocities change [UPSTREAM-RECALL]; it is what keeps a robot that is
+ * driven by 1e5 N m motors towards random targets from gaining energy without bound.  Bullet clamps
+ * the base components in the base frame, this restatement (and the kernel) in the world frame. */
+static void clamp_velocities(const hg_config *c, double *st, int n) {
+    const double vmax = c->max_coord_velocity;
+    if (!(vmax > 0)) return;
+    for (int k = 7; k < 13; k++) { if (st[k] > vmax) st[k] = vmax; if (st[k] < -vmax) st[k] = -vmax; }
+    double *qd = st + HG_STATE_BASE + n;
+    for (int i = 0; i < n; i++) { if (qd[i] > vmax) qd[i] = vmax; if (qd[i] < -vmax) qd[i] = -vmax; }
+}
+
 static int physics_step(const hg_model *m, const hg_config *c, double *st, step_info_t *info) {
     const int n = m->n_links, ndof = 6 + n;
     const double dt = c->dt;
@@ -478,6 +490,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
 
     for (int k = 0; k < 3; k++) { st[10 + k] += dt * acc[k]; st[7 + k] += dt * acc[3 + k]; }
     for (int i = 0; i < n; i++) qd[i] += dt * acc[6 + i];
+    clamp_velocities(c, st, n);
     for (int k = 0; k < 3; k++) { vel[k] = st[10 + k]; vel[3 + k] = st[7 + k]; }
     for (int i = 0; i < n; i++) vel[6 + i] = qd[i];
 
@@ -542,6 +555,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
 
     for (int k = 0; k < 3; k++) { st[10 + k] += dv[k]; st[7 + k] += dv[3 + k]; }
     for (int i = 0; i < n; i++) qd[i] += dv[6 + i];
+    clamp_velocities(c, st, n);
 
     /* integrate positions with the new velocities */
     for (int k = 0; k < 3; k++) st[k] += dt * st[7 + k];

@@ -279,3 +279,25 @@ def test_pepper_base_slots_extension():
         x = float(obs["position"][0, 0])
         assert lo < x < hi, (use, x)                  # 1 s at 0.5 * 0.55 m/s = 0.275 m, or nothing
         env.close()
+
+
+@pytest.mark.gpu
+def test_random_control_soak_stays_finite():
+    """random_control_*.py for 600 steps on 1024 envs per robot: with Bullet's velocity-coordinate clamp
+    (hg_config.max_coord_velocity) no env ever needs the non-finite reset, Dancer's 1e5 N m motors
+    included; without it (clamp off) Dancer does blow up, which is what the guard is for."""
+    from humanoid_gym_amd.workloads import random_actions
+    for name, sub, clamp, expect_resets in (("dancer", 4, 100.0, False), ("nao", 1, 100.0, False), ("dancer", 4, 0.0, True)):
+        model, cfg, sim, torch = _sim(name, 1024, max_coord_velocity=clamp)
+        rng = np.random.default_rng(7)
+        acts = [torch.tensor(random_actions(model, rng, 1024), device="cuda:0") for _ in range(4)]
+        stats = torch.zeros(8, device="cuda:0")
+        for t in range(600):
+            sim.step(acts[(t // 20) % 4], n_substeps=sub)
+        sim.stats_flush(stats)
+        assert bool(torch.isfinite(sim.get_state()).all())
+        assert stats[0].item() == 600 * 1024
+        assert (stats[2].item() > 0) == expect_resets, (name, clamp, stats.tolist())
+        if clamp > 0:
+            assert float(sim.get_state()[:, 7:13].abs().max()) <= clamp + 1e-3
+        sim.close()

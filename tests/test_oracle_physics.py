@@ -179,3 +179,20 @@ def test_config1_nao_random_control_1000_steps():
     assert np.isfinite(sim.state).all()
     assert (np.asarray(o["q"]) >= lo - 1e-6).all() and (np.asarray(o["q"]) <= hi + 0.3).all()
     assert ncs > 0
+
+
+def test_velocity_coordinates_are_clamped_like_btmultibody():
+    """hg_config.max_coord_velocity (btMultiBody::m_maxCoordinateVelocity): Dancer under full-range random
+    targets with the default 1e5 N m motors stays finite for 400 steps, and no velocity coordinate
+    leaves [-100, 100]; with the clamp off some env diverges (that is what the clamp is there for)."""
+    from humanoid_gym_amd.workloads import random_actions
+    model, cfg = load_robot("dancer")
+    n = 16
+    sim = OracleSim(model, cfg, n)
+    rng = np.random.default_rng(7)
+    acts = [random_actions(model, rng, n).astype(np.float64) for _ in range(4)]
+    vmax = 0.0
+    for t in range(400):
+        sim.step(acts[(t // 20) % 4], n_substeps=2)
+        vmax = max(vmax, float(np.abs(sim.state[:, 7:13]).max()), float(np.abs(sim.qd).max()))
+    assert np.isfinite(sim.state).all() and vmax <= 100.0

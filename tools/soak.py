@@ -1,0 +1,34 @@
+"""Soak run: thousands of steps of random control per robot; reports non-finite resets and rate."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from humanoid_gym_amd.robots import load_robot
+from humanoid_gym_amd._capi import HgSim
+from humanoid_gym_amd.workloads import random_actions
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for name, n_envs, sub, kw in (("nao", 4096, 1, {}), ("pepper", 4096, 1, {}), ("romeo", 2048, 1, {"enable_self": True}),
+                              ("dancer", 4096, 4, {}), ("dancer", 2048, 4, {"enable_self": True})):
+    model, cfg = load_robot(name)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    sim = HgSim(model, cfg, n_envs, "cuda:0")
+    rng = np.random.default_rng(7)
+    acts = [torch.tensor(random_actions(model, rng, n_envs), device="cuda:0") for _ in range(8)]
+    stats = torch.zeros(8, device="cuda:0")
+    t0 = time.perf_counter()
+    for t in range(steps):
+        sim.step(acts[(t // 20) % 8], n_substeps=sub)
+        if t % 500 == 499:
+            sim.stats_flush(stats)
+            print(f"  {name} step {t + 1}: {stats.tolist()[:4]}", flush=True)
+    sim.stats_flush(stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = stats.tolist()
+    fin = bool(torch.isfinite(sim.get_state()).all())
+    print(f"{name:7s} {kw} envs={n_envs} steps={steps}: env_steps={s[0]:.0f} done(non-finite resets)={s[2]:.0f} "
+          f"collision_steps={s[3]:.0f} finite={fin} {n_envs * steps / dt / 1e6:.1f} M env-steps/s", flush=True)
+    sim.close()
