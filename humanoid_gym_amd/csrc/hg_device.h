@@ -22,7 +22,7 @@ constexpr int CON   = 12;   // floats per contact record
 
 // DevModel::link[i][...]
 enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTIA = 22,
-       L_DAMP = 25, L_LOWER = 26, L_UPPER = 27, L_MAXIMP = 28, L_MAXVEL = 29, L_QINIT = 30 };
+       L_DAMP = 25, L_LOWER = 26, L_UPPER = 27, L_MAXIMP = 28, L_MAXVEL = 29, L_QINIT = 30, L_LIMITED = 31 };
 // DevModel::base[...]
 enum { B_MASS = 0, B_INERTIA = 1, B_POS0 = 4, B_QUAT0 = 7, B_FPOS = 11, B_FQUAT = 14 };
 
@@ -60,14 +60,14 @@ struct DevModel {
     float   frame_quat[HG_MAX_LINKS + 1][4];
 };
 
-enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16 };
+enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16, F_LIMITS = 32 };
 
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
     // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
     int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children;
     int8_t  lev_start[DMAX + 4];
-    float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp, vmax;
+    float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp, vmax, limhi;
     int8_t  sel[HG_MAX_LINKS];
 };
 

@@ -286,6 +286,7 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         lk[L_MAXIMP] = (float)fmin(m->max_force[i] * c->dt, 1e30);
         lk[L_MAXVEL] = (float)fmin(m->max_vel[i], 1e30);
         lk[L_QINIT] = (float)m->q_init[i];
+        lk[L_LIMITED] = m->joint_limited[i] ? 1.0f : 0.0f;
     }
     D->base[B_MASS] = (float)m->base_mass;
     for (int k = 0; k < 3; k++) {
@@ -455,11 +456,13 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.n_base_children = s->n_base_children;
     memcpy(P.lev_start, s->lev_start, sizeof P.lev_start);
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
-              ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0);
+              ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0) |
+              (c.enable_limits ? F_LIMITS : 0);
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];
     P.kp = (float)c.kp; P.kd = (float)c.kd; P.erp = (float)c.contact_erp; P.mu = (float)c.friction;
     P.margin = (float)c.contact_margin; P.lin_damp = (float)c.lin_damping; P.ang_damp = (float)c.ang_damping;
+    P.limhi = (float)c.limit_max_impulse;
     P.vmax = c.max_coord_velocity > 0 ? (float)c.max_coord_velocity : 3.0e38f;
     StepOut O;
     O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;

@@ -603,6 +603,21 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             tv = fminf(fmaxf(tv, -maxvel), maxvel);
             target_err = tv - qd;
         }
+        // Joint-limit rows (btMultiBodyJointLimitConstraint): one per violated bound, Jacobian +-1 on the joint
+        // (so its impulse response is +- the motor row's: the row shares the motor's lane), desired
+        // velocity 0 with the Baumgarte term -penetration * erp / dt, impulse in [0, limhi].
+        float lim_s = 0.f, lim_b = 0.f;
+        if (row_motor && (P.flags & F_LIMITS)) {
+            const float *lkl = M->link[lane];
+            if (lkl[L_LIMITED] != 0.f) {
+                const float pen_lo = q - lkl[L_LOWER], pen_hi = lkl[L_UPPER] - q;
+                float pen = 0.f;
+                if (pen_lo <= 0.f) { lim_s = 1.f; pen = pen_lo; }
+                else if (pen_hi <= 0.f) { lim_s = -1.f; pen = pen_hi; }
+                lim_b = -pen * P.erp * P.inv_dt - lim_s * qd;
+            }
+        }
+        const unsigned long long limmask = __ballot(lim_s != 0.f);       // wave-uniform
         const bool row_active = row_motor || row_contact;
         if (row_motor) {     // motor rows act on their own link
             myanc = M->anc_mask[lane];
@@ -745,7 +760,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int k = 0; k < NC3; k++) AC[k] = (NMX + k == lane) ? 0.f : -AC[k] * dinv;
             if (row_motor) { hi = cacheL[CACHE * lane + 27]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
+            // limit row of this lane's joint: z_l = lam_l + lim_k + lim_s * (z - lam_motor)
+            lim_b = lim_b * dinv - lim_s * z;
         }
+        const float lim_k = lim_b;
+        float lam_l = 0.f;
 
         // The impulses live in scalar registers (slam[i] = bits of lam_i): a row update is then
         //   cand = med3(z, lo, hi);  s_new = readlane(cand, i);  z -= A_i * s_old;  z += A_i * s_new
@@ -769,16 +788,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             z = fmaf(a_i, __int_as_float(s_new), z);
             slam[i] = s_new;
         };
-        // Bullet's row order: motor rows back to front on even sweeps and front to back on odd ones,
-        // then the contact normals, then the friction pairs of contacts that carry a normal impulse.
-        auto sweep = [&](const bool forward) {
-            if (forward) {
-#pragma unroll
-                for (int i = 0; i < NMX; ++i) row_update(i, lo, hi);
-            } else {
-#pragma unroll
-                for (int i = NMX - 1; i >= 0; --i) row_update(i, lo, hi);
-            }
+        auto contact_rows = [&]() {
             if (nc > 0) {
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
@@ -795,10 +805,77 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     }
             }
         };
+        // Bullet's row order: motor rows back to front on even sweeps and front to back on odd ones,
+        // then the contact normals, then the friction pairs of contacts that carry a normal impulse.
+        auto sweep = [&](const bool forward) {
+            if (forward) {
+#pragma unroll
+                for (int i = 0; i < NMX; ++i) row_update(i, lo, hi);
+            } else {
+#pragma unroll
+                for (int i = NMX - 1; i >= 0; --i) row_update(i, lo, hi);
+            }
+            contact_rows();
+        };
         // two sweeps per trip, so that the loop body is straight-line code in the motor rows
-        #pragma unroll 1
-        for (int it = 0; it + 1 < P.iters; it += 2) { sweep(false); sweep(true); }
-        if (P.iters & 1) sweep(false);
+        if (limmask == 0ull) {
+            #pragma unroll 1
+            for (int it = 0; it + 1 < P.iters; it += 2) { sweep(false); sweep(true); }
+            if (P.iters & 1) sweep(false);
+        } else {
+            // Some joint of this env is beyond a bound (rare, so not tuned).  A limit row lives on its
+            // joint's motor lane.  With d the change of the JOINT impulse (lim_s * change of lam_l): every
+            // other row sees it like a motor impulse on column i, the motor row of joint i itself loses d
+            // from its candidate.  The motor impulses are mirrored in a VGPR (lane i: lam of motor i) so
+            // that a run-time loop over the violated joints can read them.
+            float lamv = 0.f;
+            auto motor_update_v = [&](const int i) {
+                const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
+                const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
+                float a_i;
+                if (i < 16) a_i = AM0[i < 16 ? i : 0];
+                else if (i < 32) a_i = AM1[i >= 16 && i < 32 && i < NMX ? i - 16 : 0];
+                else a_i = AM2[i >= 32 && i < NMX ? i - 32 : 0];
+                z = fmaf(-a_i, __int_as_float(slam[i]), z);
+                z = fmaf(a_i, __int_as_float(s_new), z);
+                slam[i] = s_new;
+                asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
+                             : "+v"(lamv) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
+            };
+            auto limit_update = [&](const int i) {             // i: wave-uniform, known at run time
+                const float zl = lam_l + lim_k + lim_s * (z - lamv);
+                const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), i));
+                float a_i;
+                if constexpr (NMX <= 16) a_i = AM0[i];
+                else if constexpr (NMX <= 32) a_i = i < 16 ? AM0[i & 15] : AM1[(i - 16) % clamp16(NMX - 16)];
+                else a_i = i < 16 ? AM0[i & 15] : (i < 32 ? AM1[(i - 16) & 15] : AM2[(i - 32) % clamp16(NMX - 32)]);
+                z = fmaf(a_i, d, z);                            // a_ii = 0: lane i is handled next
+                if (lane == i) { lam_l = cand; z -= d; }
+            };
+            // Bullet's non-contact list is [limit rows..., motor rows...], walked back to front on even sweeps
+            auto sweep_limits = [&](const bool forward) {
+                if (forward) {
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update(__builtin_ctzll(mk));
+#pragma unroll
+                    for (int i = 0; i < NMX; ++i) motor_update_v(i);
+                } else {
+#pragma unroll
+                    for (int i = NMX - 1; i >= 0; --i) motor_update_v(i);
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull;) {
+                        const int i = 63 - __builtin_clzll(mk);
+                        limit_update(i);
+                        mk &= ~(1ull << i);
+                    }
+                }
+                contact_rows();
+            };
+            #pragma unroll 1
+            for (int it = 0; it + 1 < P.iters; it += 2) { sweep_limits(false); sweep_limits(true); }
+            if (P.iters & 1) sweep_limits(false);
+        }
         float lam = 0.f;
 #pragma unroll
         for (int k = 0; k < NROWS; k++)       // lane k <- lam_k: one v_mov under a one-lane EXEC (all 64 lanes are active here)
@@ -806,7 +883,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                          : "+v"(lam) : "s"(slam[k]), "i"(k < 32 ? (int)(1u << (k & 31)) : 0), "i"(k >= 32 ? (int)(1u << (k & 31)) : 0));
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
-        lamL[lane] = lam;
+        lamL[lane] = fmaf(lim_s, lam_l, lam);      // joint impulse = motor row + (signed) limit row
         wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
         V3 bang = ld3(velL), bvel = ld3(velL + 3), bpos = ld3(baseL + 9);
         float bq[4] = {baseL[48], baseL[49], baseL[50], baseL[51]};

@@ -50,6 +50,7 @@ class HgModel(C.Structure):
         ("max_force", C.c_double * HG_MAX_LINKS),
         ("max_vel", C.c_double * HG_MAX_LINKS),
         ("q_init", C.c_double * HG_MAX_LINKS),
+        ("joint_limited", C.c_int32 * HG_MAX_LINKS),
         ("base_mass", C.c_double),
         ("base_inertia", C.c_double * 3),
         ("base_pos0", C.c_double * 3),
@@ -84,7 +85,8 @@ class HgConfig(C.Structure):
         ("enable_ground", C.c_int32),
         ("enable_self", C.c_int32),
         ("clamp_targets", C.c_int32),
-        ("reserved", C.c_int32),
+        ("enable_limits", C.c_int32),
+        ("limit_max_impulse", C.c_double),
     ]
 
 
@@ -109,6 +111,8 @@ class SimConfig:
     enable_ground: bool = True
     enable_self: bool = False
     clamp_targets: bool = True
+    enable_limits: bool = True           # btMultiBodyJointLimitConstraint rows for revolute joints
+    limit_max_impulse: float = 100.0     # btMultiBodyConstraint m_maxAppliedImpulse [UPSTREAM-RECALL]
 
     def to_c(self) -> HgConfig:
         c = HgConfig()
@@ -125,6 +129,8 @@ class SimConfig:
         c.enable_ground = int(self.enable_ground)
         c.enable_self = int(self.enable_self)
         c.clamp_targets = int(self.clamp_targets)
+        c.enable_limits = int(self.enable_limits)
+        c.limit_max_impulse = self.limit_max_impulse
         return c
 
 
@@ -172,6 +178,13 @@ class FlatModel:
     @property
     def n_links(self) -> int:
         return int(self.parent.shape[0])
+
+    @property
+    def limited(self) -> np.ndarray:
+        """Per dof: URDF `revolute` with lower < upper (Bullet adds a joint-limit constraint); `continuous` not."""
+        t = [self.joint_types_all[j] for j in self.dof_joint]
+        return np.array([1 if (t[k] == "revolute" and self.lower[k] < self.upper[k]) else 0
+                         for k in range(self.n_links)], np.int32)
 
     @property
     def n_act(self) -> int:
@@ -240,6 +253,7 @@ class FlatModel:
             m.max_force[i] = float(self.max_force[i])
             m.max_vel[i] = float(self.max_vel[i])
             m.q_init[i] = float(self.q_init[i])
+            m.joint_limited[i] = int(self.limited[i])
         for k in range(self.n_act):
             m.act_joint[k] = int(self.act_joint[k])
         m.base_mass = float(self.base_mass)

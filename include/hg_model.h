@@ -58,6 +58,8 @@ typedef struct hg_model {
     double  max_force[HG_MAX_LINKS];       /* motor force bound (N m)               */
     double  max_vel[HG_MAX_LINKS];         /* motor target-velocity clamp (rad/s)   */
     double  q_init[HG_MAX_LINKS];          /* reset posture and initial targets     */
+    int32_t joint_limited[HG_MAX_LINKS];   /* 1: URDF `revolute` with lower < upper -> Bullet adds a
+                                              btMultiBodyJointLimitConstraint; 0: `continuous`     */
 
     /* base body */
     double  base_mass;
@@ -98,7 +100,8 @@ typedef struct hg_config {
     int32_t enable_ground;     /* plane z = 0                                         */
     int32_t enable_self;       /* sphere-pair self collision                          */
     int32_t clamp_targets;     /* qibullet setAngles clamps to the limits             */
-    int32_t reserved;
+    int32_t enable_limits;     /* joint-limit constraint rows for joint_limited joints */
+    double  limit_max_impulse; /* btMultiBodyConstraint m_maxAppliedImpulse, 100      */
 } hg_config;
 
 /* State record of one env: HG_STATE_BASE + 3*n values (double in the oracle,

@@ -48,7 +48,7 @@
 
 #define NL HG_MAX_LINKS
 #define NDOF_MAX (6 + HG_MAX_LINKS)
-#define NROWS_MAX (HG_MAX_LINKS + 3 * HG_MAX_CONTACTS)
+#define NROWS_MAX (2 * HG_MAX_LINKS + 3 * HG_MAX_CONTACTS)
 
 /* ------------------------------------------------------------------ */
 /* small linear algebra                                                */
@@ -494,8 +494,32 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
     for (int k = 0; k < 3; k++) { vel[k] = st[10 + k]; vel[3 + k] = st[7 + k]; }
     for (int i = 0; i < n; i++) vel[6 + i] = qd[i];
 
-    /* rows: motors, then contact normals, then friction pairs */
+    /* Non-contact rows in the order PyBullet creates them: joint-limit constraints while the URDF is
+     * converted, motors afterwards [UPSTREAM-RECALL].  btMultiBodyJointLimitConstraint: one row per
+     * violated bound (penetration = q - lower or upper - q; rows with penetration > 0 are skipped),
+     * Jacobian +-1 on the joint, desired velocity 0, Baumgarte term -penetration * erp / dt, impulse in
+     * [0, m_maxAppliedImpulse].  The response of such a row is +- that of the joint's motor row. */
     int nr = 0;
+    int lim_joint[HG_MAX_LINKS];
+    double lim_sign[HG_MAX_LINKS], lim_pen[HG_MAX_LINKS];
+    int n_lim = 0;
+    if (c->enable_limits)
+        for (int i = 0; i < n; i++) {
+            if (!m->joint_limited[i]) continue;
+            if (q[i] - m->lower[i] <= 0) { lim_joint[n_lim] = i; lim_sign[n_lim] = 1.0; lim_pen[n_lim++] = q[i] - m->lower[i]; }
+            else if (m->upper[i] - q[i] <= 0) { lim_joint[n_lim] = i; lim_sign[n_lim] = -1.0; lim_pen[n_lim++] = m->upper[i] - q[i]; }
+        }
+    for (int k = 0; k < n_lim; k++) {
+        row_t *r = &rows[nr++];
+        const int i = lim_joint[k];
+        memset(r->J, 0, sizeof(double) * ndof);
+        r->J[6 + i] = lim_sign[k];
+        impulse_response(m, &W, r->J, r->u);
+        r->diag_inv = 1.0 / (lim_sign[k] * r->u[6 + i]);
+        r->rhs = (-lim_pen[k] * c->contact_erp / dt - lim_sign[k] * qd[i]) * r->diag_inv;
+        r->lo = 0; r->hi = c->limit_max_impulse; r->lambda = 0; r->normal_row = -1;
+    }
+    const int n_noncontact = n_lim + n;
     for (int i = 0; i < n; i++) {
         row_t *r = &rows[nr++];
         memset(r->J, 0, sizeof(double) * ndof);
@@ -545,8 +569,8 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
 
     memset(dv, 0, sizeof(double) * ndof);
     for (int it = 0; it < c->solver_iters; it++) {
-        for (int j = 0; j < n; j++) {
-            const int idx = (it & 1) ? j : n - 1 - j;
+        for (int j = 0; j < n_noncontact; j++) {
+            const int idx = (it & 1) ? j : n_noncontact - 1 - j;
             resolve_row(&rows[idx], rows, c->friction, dv, ndof);
         }
         for (int j = first_normal; j < first_friction; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
