@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--robot", default="nao")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg", action="append", default=[], metavar="KEY=VALUE",
+                    help="override a SimConfig field (diagnostics only; the reported metric is the default config)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse")
     args = ap.parse_args()
     if os.environ.get("HG_BENCH_DEBUG"):     # where does a stuck rank sit?
@@ -126,6 +128,9 @@ def main():
     _dbg("process group ready")
 
     model, cfg = load_robot(args.robot)
+    for kv in args.cfg:
+        k, v = kv.split("=", 1)
+        setattr(cfg, k, type(getattr(cfg, k))(eval(v)))
     n_envs = args.envs_per_gpu
     if args.robot == "nao":
         rows, sel = synthetic_replay(model)

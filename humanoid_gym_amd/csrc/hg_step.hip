@@ -30,6 +30,15 @@ namespace hg {
 // The workgroup is ONE wavefront, whose LDS operations execute in program order, so lanes can
 // hand data to each other through LDS without s_barrier (which would also drain vmcnt).  What is
 // still needed is that hipcc does not move LDS accesses across the hand-off point.
+// The lane index, recomputed where it is needed (two VALU instructions) instead of being kept in a
+// register across the whole kernel: the volatile asm cannot be hoisted or merged, so nothing derived
+// from one call site stays live until the next.
+HG_FI int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 HG_FI void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -142,7 +151,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     for (int sub = 0; sub < P.n_substeps; ++sub) {
         // Re-derive everything lane- and size-dependent from opaque copies: without this hipcc
         // hoists hundreds of loop-invariant masks/addresses out of the substep loop and spills them.
-        int lane_v = lane_o, n_s = n_o;
+        int lane_v = fresh_lane(), n_s = n_o;
         asm volatile("" : "+v"(lane_v), "+s"(n_s) :: "memory");
         const int lane = lane_v, n = n_s;
         const int ndof = 6 + n;
@@ -482,7 +491,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             // current velocities for the contact rows
             if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
         }
-        if (is_link) velL[6 + lane] = qd;
+        if (is_link) { velL[6 + lane] = qd; accL[lane] = qd; }     // accL: parked until the end of the substep (accelerations are dead)
         wave_sync();      // region AB (pub/up) is dead from here on: Jc may overwrite it
 
         const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
@@ -760,11 +769,72 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int k = 0; k < NC3; k++) AC[k] = (NMX + k == lane) ? 0.f : -AC[k] * dinv;
             if (row_motor) { hi = cacheL[CACHE * lane + 27]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
-            // limit row of this lane's joint: z_l = lam_l + lim_k + lim_s * (z - lam_motor)
-            lim_b = lim_b * dinv - lim_s * z;
+            lim_b *= dinv;          // start value of the limit row's candidate: b_l / A_ii
         }
-        const float lim_k = lim_b;
         float lam_l = 0.f;
+
+        // Limit rows on spare lanes.  The wave has 64 - NROWS lanes without a row; up to KL of them take
+        // one violated joint limit each and become ordinary rows of the sweep (4 VALU per row and sweep).
+        // Lane L = NROWS + k of slot k mirrors motor lane i_k: its A-row is lim_s * (row i_k) with -lim_s
+        // in column i_k, and it brings one more column, aL[k] = lim_s * (column i_k) with -lim_s on lane
+        // i_k and 0 on itself.  Envs with more violated joints than slots take the generic path below.
+        constexpr int KL = (WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4;
+        const int nlim = __popcll(limmask);
+        const bool use_slots = KL > 0 && nlim > 0 && nlim <= KL;      // wave-uniform
+        float aL[KL > 0 ? KL : 1];
+        int slamL[KL > 0 ? KL : 1];
+        int slot_joint[KL > 0 ? KL : 1];
+        float slot_sign[KL > 0 ? KL : 1];
+#pragma unroll
+        for (int k = 0; k < (KL > 0 ? KL : 1); k++) { aL[k] = 0.f; slamL[k] = 0; slot_joint[k] = 0; slot_sign[k] = 0.f; }
+        if constexpr (KL > 0) {
+            if (use_slots) {
+                // slot k <- k-th violated joint (ascending); lane L_k learns its source lane, sign and start value
+                int src = lane;
+                float scale = 1.f;
+                {
+                    unsigned long long mk = limmask;
+                    const float c_all = lim_b;
+#pragma unroll
+                    for (int k = 0; k < KL; k++) {
+                        if (k < nlim) {
+                            const int i = __builtin_ctzll(mk);
+                            mk &= mk - 1ull;
+                            const float sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s), i));
+                            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_all), i));
+                            slot_joint[k] = i; slot_sign[k] = sg;
+                            if (lane == NROWS + k) { src = i; scale = sg; z = c0; lo = 0.f; hi = P.limhi; }
+                        }
+                    }
+                }
+                // every column register: the slot lanes copy their joint's entry (times the sign)
+#pragma unroll
+                for (int j = 0; j < NMX; j++) {
+                    if (j < 16) AM0[j] = scale * __shfl(AM0[j], src);
+                    else if (j < 32) AM1[j - 16] = scale * __shfl(AM1[j - 16], src);
+                    else AM2[j - 32] = scale * __shfl(AM2[j - 32], src);
+                }
+#pragma unroll
+                for (int c = 0; c < NC3; c++) AC[c] = scale * __shfl(AC[c], src);
+                // the extra columns, and the coupling of a slot with its own joint's motor row
+#pragma unroll
+                for (int k = 0; k < KL; k++) {
+                    if (k < nlim) {
+                        const int i = slot_joint[k];
+                        const float sg = slot_sign[k];
+                        float col;
+                        if constexpr (NMX <= 16) col = AM0[i];
+                        else if constexpr (NMX <= 32) col = i < 16 ? AM0[i & 15] : AM1[(i - 16) % clamp16(NMX - 16)];
+                        else col = i < 16 ? AM0[i & 15] : (i < 32 ? AM1[(i - 16) & 15] : AM2[(i - 32) % clamp16(NMX - 32)]);
+                        const float mine = lane == NROWS + k ? -sg : col;      // column i_k on lane L_k: -sign
+                        if constexpr (NMX <= 16) AM0[i] = mine;
+                        else if constexpr (NMX <= 32) { if (i < 16) AM0[i & 15] = mine; else AM1[(i - 16) % clamp16(NMX - 16)] = mine; }
+                        else { if (i < 16) AM0[i & 15] = mine; else if (i < 32) AM1[(i - 16) & 15] = mine; else AM2[(i - 32) % clamp16(NMX - 32)] = mine; }
+                        aL[k] = lane == i ? -sg : (lane == NROWS + k ? 0.f : sg * col);
+                    }
+                }
+            }
+        }
 
         // The impulses live in scalar registers (slam[i] = bits of lam_i): a row update is then
         //   cand = med3(z, lo, hi);  s_new = readlane(cand, i);  z -= A_i * s_old;  z += A_i * s_new
@@ -807,18 +877,38 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         };
         // Bullet's row order: motor rows back to front on even sweeps and front to back on odd ones,
         // then the contact normals, then the friction pairs of contacts that carry a normal impulse.
+        auto slot_update = [&](const int k) {              // limit row of slot k, lane NROWS + k
+            const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
+            const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), NROWS + (k < KL ? k : 0));
+            z = fmaf(-aL[k], __int_as_float(slamL[k]), z);
+            z = fmaf(aL[k], __int_as_float(s_new), z);
+            slamL[k] = s_new;
+        };
+        // (Bullet's non-contact list is [limit rows..., motor rows...], walked back to front on even sweeps)
         auto sweep = [&](const bool forward) {
             if (forward) {
+                if constexpr (KL > 0) {
+                    if (use_slots) {
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) if (k < nlim) slot_update(k);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < NMX; ++i) row_update(i, lo, hi);
             } else {
 #pragma unroll
                 for (int i = NMX - 1; i >= 0; --i) row_update(i, lo, hi);
+                if constexpr (KL > 0) {
+                    if (use_slots) {
+#pragma unroll
+                        for (int k = KL - 1; k >= 0; --k) if (k < nlim) slot_update(k);
+                    }
+                }
             }
             contact_rows();
         };
         // two sweeps per trip, so that the loop body is straight-line code in the motor rows
-        if (limmask == 0ull) {
+        if (limmask == 0ull || use_slots) {
             #pragma unroll 1
             for (int it = 0; it + 1 < P.iters; it += 2) { sweep(false); sweep(true); }
             if (P.iters & 1) sweep(false);
@@ -829,6 +919,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             // from its candidate.  The motor impulses are mirrored in a VGPR (lane i: lam of motor i) so
             // that a run-time loop over the violated joints can read them.
             float lamv = 0.f;
+            const float lim_k = lim_b - lim_s * z;      // z_l = lam_l + lim_k + lim_s * (z - lam_motor); z is still b_m / A_ii here
             auto motor_update_v = [&](const int i) {
                 const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
                 const int s_new = __builtin_amdgcn_readlane(__float_as_int(cand), i);
@@ -883,6 +974,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                          : "+v"(lam) : "s"(slam[k]), "i"(k < 32 ? (int)(1u << (k & 31)) : 0), "i"(k >= 32 ? (int)(1u << (k & 31)) : 0));
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
+        if constexpr (KL > 0) {
+            if (use_slots) {
+#pragma unroll
+                for (int k = 0; k < KL; k++)
+                    if (k < nlim && lane == slot_joint[k]) lam_l = __int_as_float(slamL[k]);
+            }
+        }
         lamL[lane] = fmaf(lim_s, lam_l, lam);      // joint impulse = motor row + (signed) limit row
         wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
         V3 bang = ld3(velL), bvel = ld3(velL + 3), bpos = ld3(baseL + 9);
@@ -947,7 +1045,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 wave_sync();
             }
-            qd = clampv(qd + dq, P.vmax);
+            qd = clampv((is_link ? accL[lane] : 0.f) + dq, P.vmax);   // qd was parked in LDS, q is re-read from the record
             bang = clamp3(bang + mulv(Rw0, ab.a), P.vmax);
             bvel = clamp3(bvel + mulv(Rw0, ab.l), P.vmax);
         }
@@ -955,7 +1053,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ============ 6. integrate positions ==================================================
         float dt = P.dt, inv_dt = P.inv_dt;
         asm volatile("" : "+s"(dt), "+s"(inv_dt));   // opaque: keeps dt-derived constants inside the loop
-        q = fmaf(dt, qd, q);
+        {
+            int lane_q = lane;
+            asm volatile("" : "+v"(lane_q));      // fresh address arithmetic (see the store below)
+            q = fmaf(dt, qd, lane_q < n ? st[HG_STATE_BASE + lane_q] : 0.f);
+        }
         bpos = bpos + bvel * dt;
         {
             float ang = sqrtf(dot(bang, bang));
@@ -987,6 +1089,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         wave_sync();      // the record is re-read by every lane (next substep, guard below)
     }  // substeps
 
+    {   // epilogue, with its own lane index (the kernel-level one would otherwise stay live across the substep loop)
+    const int lane = fresh_lane();
+    const bool is_link = lane < n;
     // ---- non-finite guard: reset the env in place and raise done ---------------------------------
     float q = 0.f, qd = 0.f;
     if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
@@ -1052,6 +1157,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             O.base_xyyaw[3 * (size_t)env + 1] = fp.y;
             O.base_xyyaw[3 * (size_t)env + 2] = atan2f(Rl.m[3], Rl.m[0]);
         }
+    }
     }
 }
 
