@@ -9,8 +9,10 @@
 //
 // Lane roles change per phase (FP32 VALU throughout, no MFMA: the operands are
 // 3x3 / 6x6 blocks of a tree recursion, not GEMM tiles):
-//   * kinematics and ABA: lane i owns link i; the tree is swept level by level,
-//     parent <-> child data goes through LDS;
+//   * kinematics and the root -> leaves ABA pass: lane i owns link i; the tree is swept level by
+//     level, parent <-> child data goes through LDS;
+//   * the leaves -> root ABA pass: 7 lanes per link, one per column of X^T Ia X plus one for the
+//     bias force;
 //   * contact detection: lanes stride over the collision spheres;
 //   * constraint rows: lane r owns row r (motor rows first, then contact
 //     normals, then friction pairs).  Each lane computes M^-1 J_r^T with its own
@@ -18,9 +20,11 @@
 //     broadcast ABA cache in LDS) and accumulates ITS ROW of the Delassus matrix
 //     A = J M^-1 J^T in registers;
 //   * PGS: the sweep over rows is unrolled; at row i every lane forms its own
-//     candidate impulse, lane i's change is broadcast with v_readlane and every
-//     lane j updates w_j += A[j][i] * d.  This is the impulse-space form of
-//     Bullet's velocity-space sweep (w = J dv), same iterates, no reductions;
+//     candidate impulse, lane i's new impulse is broadcast with v_readlane (the
+//     impulses live in scalar registers) and every lane j updates its candidate
+//     with A[j][i].  This is the impulse-space form of Bullet's velocity-space
+//     sweep (w = J dv), same iterates, no reductions; violated joint limits ride
+//     along as extra rows on the wave's spare lanes;
 //   * the final M^-1 J^T lambda is one more level-by-level ABA response.
 #include "hg_device.h"
 #include "hg_math.h"
@@ -753,7 +757,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // ---- 4b. projected Gauss-Seidel on impulses ------------------------------------------
         // Per lane j: z_j = lam_j + (b_j - w_j) / A_jj, the unclamped candidate impulse of row j
         // (w = A lam).  Updating row i by d changes z_j by -A_ji d / A_jj for j != i and leaves
-        // z_i unchanged, so the sweep needs one med3, one subtract, one readlane and one fma per
+        // z_i unchanged, so the sweep needs one med3, one readlane and two fmas (- old, + new impulse) per
         // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
         float z, lo = 0.f, hi = 0.f;
         {
