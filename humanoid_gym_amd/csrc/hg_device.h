@@ -13,7 +13,7 @@ namespace hg {
 
 constexpr int WAVE  = 64;
 constexpr int DMAX  = 12;   // deepest supported link (base children are depth 1)
-constexpr int NSLOT = 2;    // links whose acceleration must outlive their first child chain
+constexpr int NSLOT = 2;    // saved-acceleration slots = deepest nesting of branching links (slots are recycled)
 constexpr int LINKC = 32;   // floats per link in DevModel::link
 constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
