@@ -349,7 +349,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 2; }
+int hg_abi_version(void) { return 3; }
 
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
     if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");

@@ -42,7 +42,8 @@ typedef struct hg_sim hg_sim;
 /* Message of the last error raised on the calling thread ("" if none). */
 const char *hg_last_error(void);
 
-/* Library/ABI version, bumped on any signature change. */
+/* Library/ABI version, bumped on any signature or struct-layout change (3: hg_model.joint_limited,
+ * hg_config.max_coord_velocity / enable_limits / limit_max_impulse, hg_stats_flush, hg_set_base_velocity). */
 int hg_abi_version(void);
 
 /*
