@@ -363,11 +363,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     if (config->max_contacts < 0 || config->max_contacts > HG_MAX_CONTACTS || config->solver_iters < 0 || !(config->dt > 0))
         return fail(HG_EINVAL, "hg_create: bad config (max_contacts, solver_iters or dt)");
 
-    int ndev = 0;
-    HG_HIP(hipGetDeviceCount(&ndev));
-    if (device_id < 0 || device_id >= ndev) return fail(HG_ENODEVICE, "hg_create: no such HIP device");
-    HG_HIP(hipSetDevice(device_id));
-
+    // the model is flattened and matched to a kernel variant on the host first, so an unsupported robot is
+    // reported as such with or without a GPU
     DevModel *hm = new (std::nothrow) DevModel;
     if (!hm) return fail(HG_ENOMEM, "hg_create: host allocation failed");
     std::string why;
@@ -381,6 +378,11 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
         delete hm;
         return fail(HG_EUNSUPPORTED, "hg_create: no kernel variant for this (n_links, max_contacts, tree depth, branching)");
     }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    if (device_id < 0 || device_id >= ndev) { delete hm; return fail(HG_ENODEVICE, "hg_create: no such HIP device"); }
+    if (hipSetDevice(device_id) != hipSuccess) { delete hm; return fail(HG_ENODEVICE, "hg_create: hipSetDevice failed"); }
 
     hg_sim *s = new (std::nothrow) hg_sim;
     if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }

@@ -63,6 +63,43 @@ def test_error_paths_without_gpu():
     assert L.hg_destroy(None) == 0
 
 
+def test_unsupported_trees_are_reported_on_the_host(tmp_path):
+    """hg_create flattens the model and picks a kernel variant before it touches a device: a chain deeper
+    than 12 links and three nested forks are HG_EUNSUPPORTED (-4), a child listed before its parent is
+    HG_EINVAL (-1); supported trees (three forks in a row: the slots are recycled) get as far as the
+    device probe."""
+    import torch
+    from _random_urdf import write_random_tree
+    from humanoid_gym_amd.urdf import load_urdf
+    from humanoid_gym_amd.model import SimConfig
+    L = _capi.load_library()
+    h = C.c_void_p()
+    cc = SimConfig().to_c()
+
+    def create(model):
+        cm = model.to_c()
+        return L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h))
+
+    deep, _ = write_random_tree(str(tmp_path / "deep.urdf"), n_links=14, max_depth=14, n_chains=1, seed=1)
+    assert create(load_urdf(deep, name="deep")) == -4 and b"deeper" in L.hg_last_error()
+    ok, _ = write_random_tree(str(tmp_path / "ok.urdf"), n_links=27, max_depth=7, n_chains=3,
+                              branch_at=((0, 2), (1, 2), (2, 2)), seed=5)
+    m = load_urdf(ok, name="ok")
+    nested = load_urdf(ok, name="nested")
+    # links 0, 1 and 2 each have a second child that comes later in the order: three forks nested in one another
+    nested.parent = np.array([-1, 0, 1, 2, 2, 1, 0] + [-1] * (nested.n_links - 7), np.int32)
+    rc = create(nested)
+    assert rc == -4 and b"nested" in L.hg_last_error(), (rc, L.hg_last_error())
+    rc = create(m)
+    if torch.cuda.is_available():
+        assert rc == 0 and L.hg_destroy(h) == 0
+    else:
+        assert rc == -2
+    cm = m.to_c()
+    cm.parent[3] = 9                    # behind the back of FlatModel.check(): the library checks too
+    assert L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h)) == -1 and b"parents-first" in L.hg_last_error()
+
+
 def test_replay_workload_layout():
     m, _ = load_robot("nao")
     l, r = workloads.synthetic_h5_trajectory(m, T=240, seed=1234)
