@@ -631,12 +631,43 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         const unsigned long long limmask = __ballot(lim_s != 0.f);       // wave-uniform
-        const bool row_active = row_motor || row_contact;
-        if (row_motor) {     // motor rows act on their own link
-            myanc = M->anc_mask[lane];
-            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[lane]);
+        // Limit rows on spare lanes.  The wave has 64 - NROWS lanes without a row; up to KL of them take one
+        // violated joint limit each and become ordinary rows: lane NROWS + k (slot k) carries a row with
+        // Jacobian slot_f = +-1 on joint slot_joint[k], so the impulse-response pass below computes its
+        // A-row like any other lane's at no extra instruction.  Envs with more violated joints than
+        // slots (and the variants with no spare lane) take the generic path in the solver.
+        constexpr int KL = (WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4;
+        const int nlim = __popcll(limmask);
+        const bool use_slots = KL > 0 && nlim > 0 && nlim <= KL;      // wave-uniform
+        int slot_joint[KL > 0 ? KL : 1];
+        float slot_sign[KL > 0 ? KL : 1];
+#pragma unroll
+        for (int k = 0; k < (KL > 0 ? KL : 1); k++) { slot_joint[k] = 0; slot_sign[k] = 0.f; }
+        bool row_slot = false;
+        float slot_f = 0.f;
+        if constexpr (KL > 0) {
+            if (use_slots) {
+                unsigned long long mk = limmask;
+#pragma unroll
+                for (int k = 0; k < KL; k++) {
+                    if (k < nlim) {       // slot k <- k-th violated joint, ascending
+                        const int i = __builtin_ctzll(mk);
+                        mk &= mk - 1ull;
+                        const float sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s), i));
+                        const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_b), i));
+                        slot_joint[k] = i; slot_sign[k] = sg;
+                        if (lane == NROWS + k) { row_slot = true; slot_f = sg; body = i; target_err = b0; }
+                    }
+                }
+            }
+        }
+        const bool row_active = row_motor || row_contact || row_slot;
+        if (row_motor || row_slot) {     // motor and limit rows act on one link
+            myanc = M->anc_mask[body];
+            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
             pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
         }
+        const float unit_f = row_motor ? 1.f : slot_f;     // the one non-zero Jacobian entry of such a row
         const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
         wave_sync();
 
@@ -663,7 +694,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                     if (l >= 0) {
                         const float *pc = cacheL + CACHE * l;
-                        const float f = row_motor ? (l == lane ? 1.f : 0.f) : JcL[(6 + l) * NC3 + col];
+                        const float f = (row_motor || row_slot) ? (l == body ? unit_f : 0.f) : JcL[(6 + l) * NC3 + col];
                         const Sv Sl = ldsv(pc + 20);
                         const Sv Ul = ldsv(pc + 12);
                         Y = f - sdot(Sl, Z);
@@ -744,7 +775,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if constexpr (NMX <= 16) AM0[i] = qa;
                 else if constexpr (NMX <= 32) { if (i < 16) AM0[i] = qa; else AM1[i - 16] = qa; }
                 else { if (i < 16) AM0[i] = qa; else if (i < 32) AM1[i - 16] = qa; else AM2[i - 32] = qa; }
-                if (i == lane) diag = qa;
+                if (i == body && (row_motor || row_slot)) diag = unit_f * qa;
                 if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
 #pragma unroll
@@ -777,50 +808,16 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         float lam_l = 0.f;
 
-        // Limit rows on spare lanes.  The wave has 64 - NROWS lanes without a row; up to KL of them take
-        // one violated joint limit each and become ordinary rows of the sweep (4 VALU per row and sweep).
-        // Lane L = NROWS + k of slot k mirrors motor lane i_k: its A-row is lim_s * (row i_k) with -lim_s
-        // in column i_k, and it brings one more column, aL[k] = lim_s * (column i_k) with -lim_s on lane
-        // i_k and 0 on itself.  Envs with more violated joints than slots take the generic path below.
-        constexpr int KL = (WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4;
-        const int nlim = __popcll(limmask);
-        const bool use_slots = KL > 0 && nlim > 0 && nlim <= KL;      // wave-uniform
+        // The slot rows bring one more column each: aL[k][j] = -A[j][L_k] / A[j][j] = slot_sign * (column i_k),
+        // except on the joint's own motor lane (-slot_sign: same Jacobian entry, A[i][L] = sign * A[i][i]) and on
+        // the slot lane itself (0, the diagonal).
         float aL[KL > 0 ? KL : 1];
         int slamL[KL > 0 ? KL : 1];
-        int slot_joint[KL > 0 ? KL : 1];
-        float slot_sign[KL > 0 ? KL : 1];
 #pragma unroll
-        for (int k = 0; k < (KL > 0 ? KL : 1); k++) { aL[k] = 0.f; slamL[k] = 0; slot_joint[k] = 0; slot_sign[k] = 0.f; }
+        for (int k = 0; k < (KL > 0 ? KL : 1); k++) { aL[k] = 0.f; slamL[k] = 0; }
         if constexpr (KL > 0) {
             if (use_slots) {
-                // slot k <- k-th violated joint (ascending); lane L_k learns its source lane, sign and start value
-                int src = lane;
-                float scale = 1.f;
-                {
-                    unsigned long long mk = limmask;
-                    const float c_all = lim_b;
-#pragma unroll
-                    for (int k = 0; k < KL; k++) {
-                        if (k < nlim) {
-                            const int i = __builtin_ctzll(mk);
-                            mk &= mk - 1ull;
-                            const float sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s), i));
-                            const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_all), i));
-                            slot_joint[k] = i; slot_sign[k] = sg;
-                            if (lane == NROWS + k) { src = i; scale = sg; z = c0; lo = 0.f; hi = P.limhi; }
-                        }
-                    }
-                }
-                // every column register: the slot lanes copy their joint's entry (times the sign)
-#pragma unroll
-                for (int j = 0; j < NMX; j++) {
-                    if (j < 16) AM0[j] = scale * __shfl(AM0[j], src);
-                    else if (j < 32) AM1[j - 16] = scale * __shfl(AM1[j - 16], src);
-                    else AM2[j - 32] = scale * __shfl(AM2[j - 32], src);
-                }
-#pragma unroll
-                for (int c = 0; c < NC3; c++) AC[c] = scale * __shfl(AC[c], src);
-                // the extra columns, and the coupling of a slot with its own joint's motor row
+                if (row_slot) { lo = 0.f; hi = P.limhi; }
 #pragma unroll
                 for (int k = 0; k < KL; k++) {
                     if (k < nlim) {
@@ -830,10 +827,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         if constexpr (NMX <= 16) col = AM0[i];
                         else if constexpr (NMX <= 32) col = i < 16 ? AM0[i & 15] : AM1[(i - 16) % clamp16(NMX - 16)];
                         else col = i < 16 ? AM0[i & 15] : (i < 32 ? AM1[(i - 16) & 15] : AM2[(i - 32) % clamp16(NMX - 32)]);
-                        const float mine = lane == NROWS + k ? -sg : col;      // column i_k on lane L_k: -sign
-                        if constexpr (NMX <= 16) AM0[i] = mine;
-                        else if constexpr (NMX <= 32) { if (i < 16) AM0[i & 15] = mine; else AM1[(i - 16) % clamp16(NMX - 16)] = mine; }
-                        else { if (i < 16) AM0[i & 15] = mine; else if (i < 32) AM1[(i - 16) & 15] = mine; else AM2[(i - 32) % clamp16(NMX - 32)] = mine; }
                         aL[k] = lane == i ? -sg : (lane == NROWS + k ? 0.f : sg * col);
                     }
                 }
