@@ -190,8 +190,9 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
     X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
     X(4, 20, 8, 12, 2, 4)  /* pepper (deep chain, branching torso)     */ \
     X(5, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
-    X(6, 40, 8, 12, 2, 3)  /* romeo                                    */ \
-    X(7, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
+    X(6, 37, 8, 12, 2, 3)  /* romeo: 61 rows, 3 lanes left for limits  */ \
+    X(7, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
+    X(8, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
