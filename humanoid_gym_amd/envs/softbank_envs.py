@@ -105,12 +105,13 @@ class PepperEnv(_SoftbankEnv):
                                        np.array([1] * 3 + self.upper_limits, dtype=np.float32))
 
     def step(self, actions):                                           # pepper_env.py:56-76
-        a = np.asarray(actions.cpu() if hasattr(actions, "cpu") else actions, dtype=np.float32)
+        t = self._torch
+        # tensors stay on the device (no host round trip per step); lists / arrays go through numpy once
+        a = actions if isinstance(actions, t.Tensor) else np.asarray(actions, dtype=np.float32)
         if a.shape[-1] == len(self.joint_names) + 3:
             if self.use_base_slots:
-                t = self._torch
-                cmd = t.as_tensor(np.clip(a[..., :3], -1.0, 1.0).reshape(-1, 3) * np.asarray(self.BASE_SCALE, np.float32),
-                                  dtype=t.float32, device=self.device)
+                cmd = t.as_tensor(a[..., :3], dtype=t.float32, device=self.device).reshape(-1, 3).clamp(-1.0, 1.0)
+                cmd = cmd * t.tensor(self.BASE_SCALE, dtype=t.float32, device=self.device)
                 self.sim.set_base_velocity(cmd.expand(self.n_envs, 3) if cmd.shape[0] == 1 else cmd)
             a = a[..., 3:]                 # reference behaviour: the base slots are not consumed (pepper_env.py:61)
         obs, reward, done, _ = self._step_sim(a)
