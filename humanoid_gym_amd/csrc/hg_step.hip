@@ -174,7 +174,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         M3 E; V3 r;
         {
             float sq, cq;
-            sincosf(-q, &sq, &cq);
+            __sincosf(-q, &sq, &cq);     // v_sin/v_cos: |q| <= a few pi, absolute error ~4e-7
             E = mul(axis_rot(ax, sq, cq), ldm(lk + L_R0));
             r = ld3(lk + L_E) + mulv(E, ld3(lk + L_D));
         }
@@ -1061,9 +1061,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             if (ang * dt > 0.78539816f) ang = 0.78539816f * inv_dt;
             float f;
             if (ang < 0.001f) f = 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang;
-            else f = sinf(0.5f * ang * dt) / ang;
+            else f = __sinf(0.5f * ang * dt) / ang;
             const V3 a = bang * f;
-            const float cw = cosf(0.5f * ang * dt);
+            const float cw = __cosf(0.5f * ang * dt);
             const float x = bq[0], y = bq[1], z = bq[2], s = bq[3];
             float nq[4] = {cw * x + a.x * s + a.y * z - a.z * y,
                            cw * y - a.x * z + a.y * s + a.z * x,
