@@ -183,7 +183,7 @@ HG_FI void stsv(float *p, Sv s) { st3(p, s.a); st3(p + 3, s.l); }
 
 // inverse of a symmetric positive definite 6x6 (full storage, row-major) via Cholesky
 HG_FI void spd6_inverse(const float A[36], float Inv[36]) {
-    float L[36];
+    float L[36], rd[6];      // rd: reciprocals of the diagonal of L (no division anywhere below)
 #pragma unroll
     for (int i = 0; i < 36; i++) L[i] = 0.f;
 #pragma unroll
@@ -193,8 +193,8 @@ HG_FI void spd6_inverse(const float A[36], float Inv[36]) {
             float s = A[6 * i + j];
 #pragma unroll
             for (int k = 0; k < j; k++) s = fmaf(-L[6 * i + k], L[6 * j + k], s);
-            if (i == j) L[6 * i + i] = sqrtf(fmaxf(s, 1e-30f));
-            else L[6 * i + j] = s / L[6 * j + j];
+            if (i == j) { rd[i] = rsqrtf(fmaxf(s, 1e-30f)); L[6 * i + i] = fmaxf(s, 1e-30f) * rd[i]; }    // v_rsq_f32, 1 ulp
+            else L[6 * i + j] = s * rd[j];
         }
     }
     float Li[36];  // inverse of L (lower triangular)
@@ -207,7 +207,7 @@ HG_FI void spd6_inverse(const float A[36], float Inv[36]) {
             float s = (i == c) ? 1.f : 0.f;
 #pragma unroll
             for (int k = c; k < i; k++) s = fmaf(-L[6 * i + k], Li[6 * k + c], s);
-            Li[6 * i + c] = s / L[6 * i + i];
+            Li[6 * i + c] = s * rd[i];
         }
     }
 #pragma unroll

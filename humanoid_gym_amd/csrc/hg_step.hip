@@ -305,7 +305,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     const unsigned long long bal = __ballot(act);
                     const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
                     if (act && slot < P.maxc) {
-                        const V3 nrm = d * (1.0f / len);
+                        const V3 nrm = d * __frcp_rn(len);
                         const V3 pt = ((ca - nrm * ra) + (cb + nrm * rb)) * 0.5f;
                         float *co = conL + CON * slot;
                         co[0] = __int_as_float((int)((pr >> 16) & 0xffu) - 1);
@@ -379,7 +379,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         const V3 r = ld3(pc + 9);
                         const Sv Sm = ldsv(pc + 20);
                         const Sv U = ai_mul(IA, Sm);
-                        const float Dinv = 1.0f / sdot(Sm, U);
+                        const float Dinv = __frcp_rn(sdot(Sm, U));      // v_rcp_f32, 1 ulp
                         const float u = tau0 - sdot(Sm, pA);
                         // the vector this lane pushes through Ia = IA - U U^T / D
                         Sv w;
@@ -792,7 +792,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
         float z, lo = 0.f, hi = 0.f;
         {
-            const float dinv = (row_active && diag > 1e-20f) ? 1.0f / diag : 0.f;
+            const float dinv = (row_active && diag > 1e-20f) ? __frcp_rn(diag) : 0.f;
             z = target_err * dinv;
 #pragma unroll
             for (int k = 0; k < NMX; k++) {
