@@ -79,8 +79,19 @@ def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
     c0 = time.perf_counter(); run(4, 4); per = (time.perf_counter() - c0) / 4
     steps = int(max(8, min(400, target_seconds / max(per, 1e-6))))
     c0 = time.perf_counter(); run(steps, 8); dt = time.perf_counter() - c0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
+    out = {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+           "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
+    # single thread beside it: one env, the oracle takes its serial path below four envs
+    one = OracleSim(model, cfg, 1)
+    k = int(max(50, min(4000, 3.0 / max(per * threads / n_envs, 1e-7))))
+    for t in range(8):
+        one.step(rows[t % T_TRAJ][None], joint_sel=sel)
+    c0 = time.perf_counter()
+    for t in range(k):
+        one.step(rows[(8 + t) % T_TRAJ][None], joint_sel=sel)
+    out["single_thread"] = {"value": k / (time.perf_counter() - c0), "unit": "env-steps/s",
+                            "sample": f"1 env x {k} steps, includes the ctypes call per step"}
+    return out
 
 
 def _dbg(msg):
