@@ -20,7 +20,7 @@ _lib = None
 SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_reset", "hg_step",
            "hg_get_joint_states", "hg_get_link_states", "hg_get_contact_pairs", "hg_get_state",
            "hg_set_state", "hg_get_layout", "hg_stats_accumulate", "hg_stats_flush",
-           "hg_set_base_velocity"]
+           "hg_set_base_velocity", "hg_get_joint_torques"]
 
 
 class HgError(RuntimeError):
@@ -52,6 +52,8 @@ def load_library(path: Optional[str] = None):
     L.hg_step.argtypes = [C.c_void_p, fp, C.POINTER(C.c_int32), C.c_int, C.c_int, fp, fp, fp, fp, u8p, u8p, vp]
     L.hg_get_joint_states.restype = C.c_int
     L.hg_get_joint_states.argtypes = [C.c_void_p, fp, fp, vp]
+    L.hg_get_joint_torques.restype = C.c_int
+    L.hg_get_joint_torques.argtypes = [C.c_void_p, fp, vp]
     L.hg_get_link_states.restype = C.c_int
     L.hg_get_link_states.argtypes = [C.c_void_p, fp, fp, fp, fp, vp]
     L.hg_get_contact_pairs.restype = C.c_int
@@ -158,6 +160,13 @@ class HgSim:
         qd = t.empty_like(q)
         _check(self.L, self.L.hg_get_joint_states(self._h, _ptr(q), _ptr(qd), self._stream()), "hg_get_joint_states")
         return q, qd
+
+    def joint_torques(self):
+        """[n_envs, n_links] motor torque applied in the last physics step (getJointState()[3])."""
+        t = self.torch
+        tau = t.empty(self.n_envs, self.n, dtype=t.float32, device=self.device)
+        _check(self.L, self.L.hg_get_joint_torques(self._h, _ptr(tau), self._stream()), "hg_get_joint_torques")
+        return tau
 
     def link_states(self):
         t = self.torch

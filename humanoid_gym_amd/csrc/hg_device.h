@@ -79,6 +79,7 @@ struct StepOut {
     int32_t *counts;                 // internal [n_envs]
     const float *base_cmd;           // internal [n_envs][3] commanded base (vx, vy, yaw rate), used with F_BASECMD
     float   *cum;                    // internal [n_envs][4]: running {steps, reward, done, collision} since the last flush
+    float   *torque;                 // internal [n_envs][n]: motor impulse / dt of the last physics step
 };
 
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.

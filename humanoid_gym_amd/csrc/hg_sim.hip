@@ -33,12 +33,13 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ---------------------------------------------------------------------------------------
 // helper kernels
 // ---------------------------------------------------------------------------------------
-__global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__ state,
+__global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__ state, float *__restrict__ torque,
                              const uint8_t *__restrict__ mask, int n_envs) {
     const int env = blockIdx.x;
     if (env >= n_envs || (mask && !mask[env])) return;
     const int n = M->n, S = HG_STATE_SIZE(n);
     float *st = state + (size_t)env * S;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) torque[(size_t)env * n + k] = 0.f;
     for (int k = threadIdx.x; k < S; k += blockDim.x) {
         float v = 0.f;
         if (k < 3) v = M->base[B_POS0 + k];
@@ -175,6 +176,7 @@ struct hg_sim {
     unsigned long long *d_link_mask = nullptr;
     int32_t *d_pairs = nullptr, *d_counts = nullptr;
     float *d_cum = nullptr;            // [n_envs][4] running episode statistics
+    float *d_torque = nullptr;         // [n_envs][n] applied motor torque of the last physics step
     float *d_base_cmd = nullptr;       // [n_envs][3] commanded base velocity, allocated on first use
     bool base_cmd_on = false;
 };
@@ -350,7 +352,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 3; }
+int hg_abi_version(void) { return 4; }
 
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
     if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");
@@ -400,11 +402,13 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(&s->d_cum, sizeof(float) * 4 * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMalloc(&s->d_torque, sizeof(float) * (size_t)n_envs * n);
     if (e == hipSuccess) e = hipMemcpy(s->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_cum, 0, sizeof(float) * 4 * (size_t)n_envs);
+    if (e == hipSuccess) e = hipMemset(s->d_torque, 0, sizeof(float) * (size_t)n_envs * n);
     delete hm;
     if (e != hipSuccess) {
         const std::string msg = std::string("hg_create: ") + hipGetErrorString(e);
@@ -423,6 +427,7 @@ int hg_destroy(hg_sim *s) {
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_model); (void)hipFree(s->d_state); (void)hipFree(s->d_link_mask);
     (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts); (void)hipFree(s->d_cum); (void)hipFree(s->d_base_cmd);
+    (void)hipFree(s->d_torque);
     delete s;
     return HG_OK;
 }
@@ -431,7 +436,7 @@ int hg_reset(hg_sim *s, const uint8_t *env_mask_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_reset: null handle");
     HG_HIP(hipSetDevice(s->device));
     hipLaunchKernelGGL(reset_kernel, dim3(s->n_envs), dim3(WAVE), 0, (hipStream_t)stream,
-                       s->d_model, s->d_state, env_mask_dev, s->n_envs);
+                       s->d_model, s->d_state, s->d_torque, env_mask_dev, s->n_envs);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }
@@ -471,6 +476,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     O.obs_q = obs_q_dev; O.obs_qd = obs_qd_dev; O.base_xyyaw = base_xyyaw_dev; O.reward = reward_dev;
     O.done = done_dev; O.collision = collision_dev;
     O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts; O.cum = s->d_cum; O.base_cmd = s->d_base_cmd;
+    O.torque = s->d_torque;
     HG_HIP(hipSetDevice(s->device));
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
@@ -490,6 +496,14 @@ int hg_get_joint_states(hg_sim *s, float *q_dev, float *qd_dev, void *stream) {
     hipLaunchKernelGGL(joint_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        s->d_state, q_dev, qd_dev, s->n, s->n_envs);
     HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+int hg_get_joint_torques(hg_sim *s, float *tau_dev, void *stream) {
+    if (!s || !tau_dev) return fail(HG_EINVAL, "hg_get_joint_torques: null argument");
+    HG_HIP(hipSetDevice(s->device));
+    HG_HIP(hipMemcpyAsync(tau_dev, s->d_torque, sizeof(float) * (size_t)s->n_envs * s->n, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
     return HG_OK;
 }
 

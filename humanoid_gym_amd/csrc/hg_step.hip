@@ -970,6 +970,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
                          : "+v"(lam) : "s"(slam[k]), "i"(k < 32 ? (int)(1u << (k & 31)) : 0), "i"(k >= 32 ? (int)(1u << (k & 31)) : 0));
 
+        {   // getJointState()[3]: the motor torque applied in this physics step (dancer_env.py:24)
+            int lane_t = lane;
+            asm volatile("" : "+v"(lane_t));      // fresh address arithmetic
+            if (lane_t < n) O.torque[(size_t)env * n + lane_t] = lam * P.inv_dt;
+        }
+
         // ============ 5. velocities += M^-1 J^T lambda =========================================
         if constexpr (KL > 0) {
             if (use_slots) {
@@ -1105,7 +1111,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         bpos = ld3(M->base + B_POS0);
 #pragma unroll
         for (int k = 0; k < 4; k++) bq[k] = M->base[B_QUAT0 + k];
-        if (is_link) { st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = 0.f; st[HG_STATE_BASE + 2 * n + lane] = q; }
+        if (is_link) {
+            st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = 0.f; st[HG_STATE_BASE + 2 * n + lane] = q;
+            O.torque[(size_t)env * n + lane] = 0.f;
+        }
         if (lane == 0) {
             st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];
             st3(st + 7, v3(0, 0, 0)); st3(st + 10, v3(0, 0, 0));

@@ -58,15 +58,18 @@ class DancerEnv(BatchedHumanoidEnv):
 
     # -- what the reference hands to custom_reward ------------------------------
     def joint_states(self):
-        """name -> (position, velocity, reactionForces(6 zeros), appliedTorque 0) like getJointState."""
+        """name -> (position, velocity, reactionForces, appliedJointMotorTorque) like getJointState
+        (dancer_env.py:24).  reactionForces is six zeros, as in the reference, which never enables the
+        joint force/torque sensors."""
         q, qd = self.sim.joint_states()
+        tau = self.sim.joint_torques()
         out = {}
         for name in self.joint_names:
             k = self.model.dof_of(name)
             if self.batched:
-                out[name] = (q[:, k], qd[:, k], (0.0,) * 6, 0.0)
+                out[name] = (q[:, k], qd[:, k], (0.0,) * 6, tau[:, k])
             else:
-                out[name] = (float(q[0, k]), float(qd[0, k]), (0.0,) * 6, 0.0)
+                out[name] = (float(q[0, k]), float(qd[0, k]), (0.0,) * 6, float(tau[0, k]))
         return out
 
     def link_states(self):

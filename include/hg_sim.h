@@ -43,7 +43,8 @@ typedef struct hg_sim hg_sim;
 const char *hg_last_error(void);
 
 /* Library/ABI version, bumped on any signature or struct-layout change (3: hg_model.joint_limited,
- * hg_config.max_coord_velocity / enable_limits / limit_max_impulse, hg_stats_flush, hg_set_base_velocity). */
+ * hg_config.max_coord_velocity / enable_limits / limit_max_impulse, hg_stats_flush, hg_set_base_velocity;
+ * 4: hg_get_joint_torques). */
 int hg_abi_version(void);
 
 /*
@@ -98,6 +99,12 @@ int hg_step(hg_sim *sim, const float *actions_dev, const int32_t *joint_sel, int
 /* Positions and velocities of ALL dofs, [n_envs][n_links] each (nullable).
  * Replaces the p.getJointState loop, dancer_env.py:22-24. */
 int hg_get_joint_states(hg_sim *sim, float *q_dev, float *qd_dev, void *stream);
+
+/* Motor torque applied to every dof during the last physics step, [n_envs][n_links]: the motor row's
+ * impulse / dt, i.e. getJointState()[3] (appliedJointMotorTorque), dancer_env.py:24.  The other entry of
+ * that tuple, the joint reaction forces [6], is all zeros in the reference (it never enables the joint
+ * force/torque sensors), so there is nothing to compute for it.  Zero after hg_reset. */
+int hg_get_joint_torques(hg_sim *sim, float *tau_dev, void *stream);
 
 /*
  * World poses of every body, [n_envs][n_links+1] records, body 0 = base:

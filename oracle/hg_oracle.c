@@ -461,6 +461,7 @@ typedef struct {
     uint64_t link_mask;                    /* bit i+1: link i has a contact, bit 0: base */
     int pair_a[HG_MAX_CONTACTS], pair_b[HG_MAX_CONTACTS];  /* body indices, -2 = ground */
     double lambda_n[HG_MAX_CONTACTS];
+    double motor_torque[HG_MAX_LINKS];     /* motor row impulse / dt of the last physics step (getJointState()[3]) */
 } step_info_t;
 
 /* btMultiBody::applyDeltaVeeMultiDof clamps every velocity coordinate to +-m_maxCoordinateVelocity
@@ -608,6 +609,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
     }
 
     if (info) {
+        for (int i = 0; i < n; i++) info->motor_torque[i] = rows[n_lim + i].lambda / dt;
         info->n_contacts = nc;
         info->link_mask = 0;
         for (int k = 0; k < nc; k++) {
@@ -665,11 +667,12 @@ void hgo_reset(const hg_model *m, double *state, int n_envs) {
  *   link_mask [n_envs] bit b: body b-1 touched something in the LAST substep
  *   pairs [n_envs][HG_MAX_CONTACTS][2], n_contacts [n_envs]  (nullable)
  */
-int hgo_step_cmd(const hg_model *m, const hg_config *c, int n_envs, double *state,
-                 const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
-                 double *obs_q, double *obs_qd, double *base_xyyaw,
-                 uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts,
-                 const double *base_cmd /* [n_envs][3] or NULL */) {
+int hgo_step_full(const hg_model *m, const hg_config *c, int n_envs, double *state,
+                  const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
+                  double *obs_q, double *obs_qd, double *base_xyyaw,
+                  uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts,
+                  const double *base_cmd /* [n_envs][3] or NULL */,
+                  double *motor_torque /* [n_envs][n_links] or NULL: getJointState()[3] */) {
     const int n = m->n_links, S = HG_STATE_SIZE(n);
     if (joint_sel == NULL) { joint_sel = m->act_joint; n_sel = m->n_act; }
     for (int k = 0; k < n_sel; k++)
@@ -711,6 +714,7 @@ int hgo_step_cmd(const hg_model *m, const hg_config *c, int n_envs, double *stat
             base_xyyaw[3 * e + 1] = st[1] + t[1];
             base_xyyaw[3 * e + 2] = atan2(Rl[3], Rl[0]);
         }
+        if (motor_torque) for (int i = 0; i < n; i++) motor_torque[(size_t)e * n + i] = info.motor_torque[i];
         if (collision) collision[e] = (info.link_mask >> 1) != 0;
         if (link_mask) link_mask[e] = info.link_mask;
         if (n_contacts) n_contacts[e] = info.n_contacts;
@@ -721,6 +725,15 @@ int hgo_step_cmd(const hg_model *m, const hg_config *c, int n_envs, double *stat
             }
     }
     return err ? -1 : 0;
+}
+
+int hgo_step_cmd(const hg_model *m, const hg_config *c, int n_envs, double *state,
+                 const double *actions, const int32_t *joint_sel, int n_sel, int n_substeps,
+                 double *obs_q, double *obs_qd, double *base_xyyaw,
+                 uint8_t *collision, uint64_t *link_mask, int32_t *pairs, int32_t *n_contacts,
+                 const double *base_cmd) {
+    return hgo_step_full(m, c, n_envs, state, actions, joint_sel, n_sel, n_substeps, obs_q, obs_qd, base_xyyaw,
+                         collision, link_mask, pairs, n_contacts, base_cmd, NULL);
 }
 
 int hgo_step(const hg_model *m, const hg_config *c, int n_envs, double *state,

@@ -46,6 +46,8 @@ def lib():
         L.hgo_step.restype = C.c_int
         L.hgo_step_cmd.argtypes = L.hgo_step.argtypes + [dp]
         L.hgo_step_cmd.restype = C.c_int
+        L.hgo_step_full.argtypes = L.hgo_step_cmd.argtypes + [dp]
+        L.hgo_step_full.restype = C.c_int
         L.hgo_link_states.argtypes = [C.POINTER(HgModel), dp, C.c_int, dp, dp, dp, dp]
         L.hgo_link_states.restype = None
         L.hgo_forward_dynamics.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp, dp]
@@ -111,16 +113,17 @@ class OracleSim:
         cmd = None
         if base_cmd is not None:
             cmd = np.ascontiguousarray(base_cmd, np.float64).reshape(self.n_envs, 3)
-        rc = lib().hgo_step_cmd(C.byref(self.cm), C.byref(self.cc), self.n_envs, _dp(self.state), _dp(act),
-                                sel_p, n_sel, n_substeps, _dp(obs_q), _dp(obs_qd), _dp(xyyaw),
-                                col.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                mask.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                pairs.ctypes.data_as(C.POINTER(C.c_int32)),
-                                nc.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cmd))
+        tau = np.zeros((self.n_envs, self.n))
+        rc = lib().hgo_step_full(C.byref(self.cm), C.byref(self.cc), self.n_envs, _dp(self.state), _dp(act),
+                                 sel_p, n_sel, n_substeps, _dp(obs_q), _dp(obs_qd), _dp(xyyaw),
+                                 col.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                 mask.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 pairs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 nc.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cmd), _dp(tau))
         if rc:
             raise RuntimeError(f"hgo_step failed: {rc}")
         return dict(q=obs_q, qd=obs_qd, base_xyyaw=xyyaw, collision=col, link_mask=mask,
-                    pairs=pairs, n_contacts=nc)
+                    pairs=pairs, n_contacts=nc, motor_torque=tau)
 
     def link_states(self):
         nb = self.n + 1

@@ -415,3 +415,38 @@ def test_joint_limit_rows(name, n_violate):
                 cpu.state[:] = cpu.state.astype(np.float32)
                 gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
         gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dancer", "nao", "pepper"])
+def test_applied_motor_torque(name):
+    """hg_get_joint_torques = getJointState()[3] (dancer_env.py:24): the motor row's impulse / dt of the
+    last physics step, against the oracle's, from shared states with random targets; zero after reset."""
+    n_envs = 8
+    model, cfg, gpu, cpu, torch = _mk(name, n_envs)
+    assert float(gpu.joint_torques().abs().max()) == 0.0
+    rng = np.random.default_rng(21)
+    lo, hi = np.asarray(model.lower)[model.act_joint], np.asarray(model.upper)[model.act_joint]
+    lo, hi = np.maximum(lo, -1.5), np.minimum(hi, 1.5)
+    worst, scale_seen = 0.0, 0.0
+    for t in range(40):
+        if t % 8 == 0:
+            act = rng.uniform(lo, hi, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
+        cpu.state[:] = cpu.state.astype(np.float32)
+        gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+        o = cpu.step(act)
+        gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))
+        _, counts, _ = gpu.contact_pairs()
+        tau = gpu.joint_torques().cpu().numpy()
+        for e in range(n_envs):
+            if counts[e].item() != o["n_contacts"][e]:
+                continue                  # a sphere within FP32 rounding of the margin: different row sets
+            scale = max(1.0, float(np.abs(o["motor_torque"][e]).max()))
+            scale_seen = max(scale_seen, scale)
+            worst = max(worst, float(np.abs(tau[e] - o["motor_torque"][e]).max()) / scale)
+    assert scale_seen > 1.0                                    # the motors did something
+    assert worst < 5e-3, worst                                 # relative to the env's largest torque
+    fmax = np.asarray(model.max_force)
+    assert (np.abs(tau) <= fmax[None, :] * (1 + 1e-5) + 1e-6).all()      # |impulse| <= max_force * dt
+    gpu.reset()
+    assert float(gpu.joint_torques().abs().max()) == 0.0

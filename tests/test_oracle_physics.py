@@ -196,3 +196,28 @@ def test_velocity_coordinates_are_clamped_like_btmultibody():
         sim.step(acts[(t // 20) % 4], n_substeps=2)
         vmax = max(vmax, float(np.abs(sim.state[:, 7:13]).max()), float(np.abs(sim.qd).max()))
     assert np.isfinite(sim.state).all() and vmax <= 100.0
+
+
+@pytest.mark.parametrize("name", ["dancer", "nao"])
+def test_motor_torque_is_the_impulse_that_moved_the_robot(name):
+    """getJointState()[3] (dancer_env.py:24): from rest, without gravity or contacts, the velocity after one
+    step must be M^-1 applied to the generalized impulse (0 on the base, motor torque * dt on the joints),
+    and no motor may exceed its force limit."""
+    model, cfg = load_robot(name)
+    cfg.enable_ground = False; cfg.gravity = (0.0, 0.0, 0.0); cfg.enable_limits = False
+    sim = OracleSim(model, cfg, 1)
+    n = model.n_links
+    rng = np.random.default_rng(8)
+    idx = np.asarray(model.act_joint)
+    tgt = np.clip(model.q_init[idx] + rng.uniform(-0.3, 0.3, len(idx)), model.lower[idx], model.upper[idx])
+    st0 = sim.state.copy()
+    o = sim.step(tgt[None])
+    tau = o["motor_torque"][0]
+    assert np.abs(tau).max() > 1e-3
+    assert (np.abs(tau) <= np.asarray(model.max_force) * (1 + 1e-12)).all()
+    st1 = sim.state.copy()
+    sim.state[:] = st0                                   # M^-1 at the pose the step started from
+    dv = sim.apply_minv(np.concatenate([np.zeros(6), tau * cfg.dt]))
+    sim.state[:] = st1
+    vel = np.concatenate([st1[0, 10:13], st1[0, 7:10], st1[0, 13 + n:13 + 2 * n]])   # (angular, linear, joints)
+    assert np.abs(vel - dv).max() < 1e-9 * max(1.0, np.abs(dv).max()), np.abs(vel - dv).max()
