@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cfg", action="append", default=[], metavar="KEY=VALUE",
                     help="override a SimConfig field (diagnostics only; the reported metric is the default config)")
+    ap.add_argument("--stream-groups", type=int, default=2,
+                    help="env groups of the extra `pipelined` measurement (0 = skip it); `value` is always one launch per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse")
     args = ap.parse_args()
     if os.environ.get("HG_BENCH_DEBUG"):     # where does a stuck rank sit?
@@ -196,6 +198,35 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / kreps
     _, counts, _ = sim.contact_pairs()
     mean_contacts = float(counts.float().mean().item())
+
+    # Beside the headline: the same envs as G handles on G streams, not joined between steps
+    # (humanoid_gym_amd/groups.py) -- the replay has no observation -> action dependency, so steps of
+    # different groups may overlap; same work per step, statistics flushed at the same cadence.
+    pipelined = None
+    if args.stream_groups > 1:
+        from humanoid_gym_amd.groups import SimGroups
+        grp = SimGroups(model, cfg, n_envs, args.stream_groups, dev)
+        gstats = torch.zeros(4, dtype=torch.float32, device=dev)
+
+        def gstep(t):
+            grp.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1, order_after_caller=False)
+            if (t + 1) % 16 == 0:
+                grp.stats_flush(gstats)
+        for t in range(args.warmup):
+            gstep(t)
+        grp.wait(); torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for t in range(args.warmup, args.warmup + args.steps):
+            gstep(t)
+        grp.stats_flush(gstats)
+        grp.wait(); torch.cuda.synchronize()
+        g_el = time.perf_counter() - g0
+        pipelined = {"stream_groups": args.stream_groups, "value_this_rank": n_envs * args.steps / g_el,
+                     "unit": "env-steps/s", "ms_per_step": g_el / args.steps * 1e3,
+                     "state_finite": bool(torch.isfinite(grp.get_state()).all().item()),
+                     "note": "same envs and steps as `value`, split into handles on their own streams and not "
+                             "joined between steps; `value` itself is one launch per step"}
+        grp.close()
     finite = bool(torch.isfinite(sim.get_state()).all().item())
 
     if rank == 0:
@@ -231,6 +262,8 @@ def main():
             "valu": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                      "algorithmic_flops_per_env_step": flops_step},
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
         print(json.dumps(out))

@@ -301,3 +301,39 @@ def test_random_control_soak_stays_finite():
         if clamp > 0:
             assert float(sim.get_state()[:, 7:13].abs().max()) <= clamp + 1e-3
         sim.close()
+
+
+@pytest.mark.gpu
+def test_env_groups_on_streams_are_bit_identical_to_one_handle():
+    """SimGroups (G handles on G streams, no join between steps) must produce, env for env, exactly what one
+    handle over all envs produces: envs are independent, only the schedule differs."""
+    import torch
+    from humanoid_gym_amd._capi import HgSim
+    from humanoid_gym_amd.groups import SimGroups
+    from humanoid_gym_amd.robots import load_robot
+    model, cfg = load_robot("nao")
+    n_envs = 50                                   # uneven split: 12 / 13 / 12 / 13
+    one = HgSim(model, cfg, n_envs, "cuda:0")
+    grp = SimGroups(model, cfg, n_envs, groups=4, device="cuda:0")
+    assert grp.bounds[0] == 0 and grp.bounds[-1] == n_envs and len(grp.sims) == 4
+    rng = np.random.default_rng(31)
+    idx = np.asarray(model.act_joint)
+    for t in range(40):
+        act = torch.tensor(rng.uniform(model.lower[idx], model.upper[idx], (n_envs, model.n_act)),
+                           dtype=torch.float32, device="cuda:0")
+        one.step(act)
+        grp.step(act)
+        if t % 8 == 7:
+            grp.wait()
+            assert torch.equal(grp.obs_q, one.obs_q) and torch.equal(grp.obs_qd, one.obs_qd)
+            assert torch.equal(grp.collision, one.collision) and torch.equal(grp.done, one.done)
+    assert torch.equal(grp.get_state(), one.get_state())
+    mask = torch.zeros(n_envs, dtype=torch.uint8, device="cuda:0")
+    mask[5] = 1; mask[30] = 1
+    one.reset(mask); grp.reset(mask)
+    assert torch.equal(grp.get_state(), one.get_state())
+    stats_g = torch.zeros(4, device="cuda:0"); stats_o = torch.zeros(4, device="cuda:0")
+    grp.stats_flush(stats_g); one.stats_flush(stats_o)
+    grp.wait(); torch.cuda.synchronize()
+    assert torch.equal(stats_g, stats_o) and float(stats_o[0]) == 40 * n_envs
+    grp.close(); one.close()
