@@ -204,29 +204,32 @@ def main():
     # different groups may overlap; same work per step, statistics flushed at the same cadence.
     pipelined = None
     if args.stream_groups > 1:
-        from humanoid_gym_amd.groups import SimGroups
-        grp = SimGroups(model, cfg, n_envs, args.stream_groups, dev)
-        gstats = torch.zeros(4, dtype=torch.float32, device=dev)
+        try:          # an extra beside the headline: it must never take the bench line down with it
+            from humanoid_gym_amd.groups import SimGroups
+            grp = SimGroups(model, cfg, n_envs, args.stream_groups, dev)
+            gstats = torch.zeros(4, dtype=torch.float32, device=dev)
 
-        def gstep(t):
-            grp.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1, order_after_caller=False)
-            if (t + 1) % 16 == 0:
-                grp.stats_flush(gstats)
-        for t in range(args.warmup):
-            gstep(t)
-        grp.wait(); torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        for t in range(args.warmup, args.warmup + args.steps):
-            gstep(t)
-        grp.stats_flush(gstats)
-        grp.wait(); torch.cuda.synchronize()
-        g_el = time.perf_counter() - g0
-        pipelined = {"stream_groups": args.stream_groups, "value_this_rank": n_envs * args.steps / g_el,
-                     "unit": "env-steps/s", "ms_per_step": g_el / args.steps * 1e3,
-                     "state_finite": bool(torch.isfinite(grp.get_state()).all().item()),
-                     "note": "same envs and steps as `value`, split into handles on their own streams and not "
-                             "joined between steps; `value` itself is one launch per step"}
-        grp.close()
+            def gstep(t):
+                grp.step(actions[t % T_TRAJ], joint_sel=sel, n_substeps=1, order_after_caller=False)
+                if (t + 1) % 16 == 0:
+                    grp.stats_flush(gstats)
+            for t in range(args.warmup):
+                gstep(t)
+            grp.wait(); torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            for t in range(args.warmup, args.warmup + args.steps):
+                gstep(t)
+            grp.stats_flush(gstats)
+            grp.wait(); torch.cuda.synchronize()
+            g_el = time.perf_counter() - g0
+            pipelined = {"stream_groups": args.stream_groups, "value_this_rank": n_envs * args.steps / g_el,
+                         "unit": "env-steps/s", "ms_per_step": g_el / args.steps * 1e3,
+                         "state_finite": bool(torch.isfinite(grp.get_state()).all().item()),
+                         "note": "same envs and steps as `value`, split into handles on their own streams and not "
+                                 "joined between steps; `value` itself is one launch per step"}
+            grp.close()
+        except Exception as e:      # noqa: BLE001
+            pipelined = {"error": f"{type(e).__name__}: {e}"}
     finite = bool(torch.isfinite(sim.get_state()).all().item())
 
     if rank == 0:
