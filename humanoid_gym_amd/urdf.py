@@ -17,10 +17,14 @@ along the principal axes of inertia (a Jacobi sweep over the 3x3 tensor, only
 when the tensor has off-diagonal terms), which is what Bullet's URDF importer
 does before it builds a btMultiBody.
 
-Collision: meshes are reduced to the 8 corners of their link-frame bounding box
-(ground contact) plus up to 3 inscribed spheres along the longest box axis
-(self contact); ``<box>``, ``<sphere>`` and ``<cylinder>`` are handled
-analytically.
+Collision: Bullet turns a collision mesh into the convex hull of its vertices, and a
+hull meets the ground plane at its support vertices.  Here a mesh is reduced to (up to)
+8 of its own vertices -- the support vertices of the hull in the eight diagonal
+directions of its link-frame bounding box, i.e. the mesh vertices nearest the box
+corners (ground contact; points on the hull, never outside it) -- plus up to 3
+inscribed spheres along the longest box axis (self contact).  When only bounds are
+known (``mesh_aabbs``) the box corners themselves are used.  ``<box>``, ``<sphere>``
+and ``<cylinder>`` are handled analytically.
 """
 from __future__ import annotations
 
@@ -134,8 +138,8 @@ def principal_axes(I: np.ndarray, threshold: float = 1e-6, max_steps: int = 30) 
 # ----------------------------------------------------------------------------
 # geometry helpers
 # ----------------------------------------------------------------------------
-def stl_aabb(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[Tuple[np.ndarray, np.ndarray]]:
-    """Axis-aligned bounds of a binary (or ASCII) STL; None if the file is absent."""
+def stl_vertices(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[np.ndarray]:
+    """Vertices [k, 3] of a binary (or ASCII) STL; None if the file is absent."""
     if not os.path.isfile(path):
         return None
     with open(path, "rb") as f:
@@ -153,17 +157,44 @@ def stl_aabb(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[Tuple[np
         if not pts:
             return None
         verts = np.array(pts, dtype=np.float64)
-    verts = verts * np.asarray(scale, dtype=np.float64)
-    return verts.min(0), verts.max(0)
+    return verts * np.asarray(scale, dtype=np.float64)
 
 
-def _box_spheres(lo: np.ndarray, hi: np.ndarray, self_spheres: bool):
-    """8 corner points (ground) + inscribed spheres along the longest axis (self)."""
+def stl_aabb(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """Axis-aligned bounds of a binary (or ASCII) STL; None if the file is absent."""
+    verts = stl_vertices(path, scale)
+    return None if verts is None else (verts.min(0), verts.max(0))
+
+
+def hull_support_points(verts: np.ndarray) -> List[np.ndarray]:
+    """Support vertices of the convex hull of ``verts`` in the 8 diagonal directions of its
+    bounding box (each direction scaled by the inverse half extents, so that a slab still
+    yields its corners), in the corner order of ``_box_spheres``; duplicates are dropped.
+    The support vertex of a hull is a vertex of the point set, so no hull is constructed."""
+    lo, hi = verts.min(0), verts.max(0)
+    h = np.maximum(0.5 * (hi - lo), 1e-9)
+    c = 0.5 * (lo + hi)
+    out: List[np.ndarray] = []
+    for sx in (-1.0, 1.0):
+        for sy in (-1.0, 1.0):
+            for sz in (-1.0, 1.0):
+                d = np.array([sx, sy, sz]) / h
+                v = verts[int(np.argmax((verts - c) @ d))]
+                if not any(np.array_equal(v, o) for o in out):
+                    out.append(v.copy())
+    return out
+
+
+def _box_spheres(lo: np.ndarray, hi: np.ndarray, self_spheres: bool, ground_points=None):
+    """Ground points (``ground_points``, else the 8 box corners) + inscribed spheres along the longest axis (self)."""
     out = []
-    for ix in (lo[0], hi[0]):
-        for iy in (lo[1], hi[1]):
-            for iz in (lo[2], hi[2]):
-                out.append((np.array([ix, iy, iz]), 0.0, SPHERE_GROUND))
+    if ground_points is not None:
+        out = [(np.asarray(p, float), 0.0, SPHERE_GROUND) for p in ground_points]
+    else:
+        for ix in (lo[0], hi[0]):
+            for iy in (lo[1], hi[1]):
+                for iz in (lo[2], hi[2]):
+                    out.append((np.array([ix, iy, iz]), 0.0, SPHERE_GROUND))
     if self_spheres:
         c = 0.5 * (lo + hi)
         h = 0.5 * (hi - lo)
@@ -376,16 +407,19 @@ def load_urdf(path: str,
                 continue
             mesh, box, sph, cyl = g.find("mesh"), g.find("box"), g.find("sphere"), g.find("cylinder")
             if mesh is not None:
-                bounds = None
+                bounds, pts = None, None
                 if mesh_aabbs and ln in mesh_aabbs:
                     bounds = (np.array(mesh_aabbs[ln][0], float), np.array(mesh_aabbs[ln][1], float))
                 else:
                     fn = mesh.get("filename").replace("package://", "")
-                    bounds = stl_aabb(os.path.join(urdf_dir, fn), _floats(mesh.get("scale"), 3, 1.0))
+                    verts = stl_vertices(os.path.join(urdf_dir, fn), _floats(mesh.get("scale"), 3, 1.0))
+                    if verts is not None:
+                        bounds = (verts.min(0), verts.max(0))
+                        pts = hull_support_points(verts)
                 if bounds is None:
                     missing_meshes.append(ln)
                     continue
-                shapes = _box_spheres(bounds[0], bounds[1], True)
+                shapes = _box_spheres(bounds[0], bounds[1], True, pts)
             elif box is not None:
                 h = 0.5 * np.array(_floats(box.get("size"), 3))
                 shapes = _box_spheres(-h, h, True)

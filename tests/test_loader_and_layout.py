@@ -145,3 +145,48 @@ def test_mimic_tags_are_recorded(tmp_path):
     assert m.parent[m.dof_of("LFinger11")] == m.dof_of("LHand")
     plain, _ = load_robot("nao")
     assert plain.meta["mimic"] == {}
+
+
+def test_hull_support_points_are_vertices_of_the_point_set():
+    """Mesh collision geometry: ground points are support vertices of the mesh's convex hull
+    in the 8 bounding-box diagonals -- members of the vertex set, equal to the corners for a box, and
+    strictly inside the bounding box for a rounded body."""
+    from humanoid_gym_amd.urdf import hull_support_points
+    rng = np.random.default_rng(5)
+    box = np.array([[x, y, z] for x in (-0.1, 0.2) for y in (-0.3, 0.05) for z in (0.0, 0.02)])
+    cloud = np.vstack([box, box.mean(0) + 0.3 * (rng.random((200, 3)) - 0.5) * (box.max(0) - box.min(0))])
+    pts = hull_support_points(cloud)
+    assert len(pts) == 8 and np.abs(np.array(pts) - box).max() == 0.0       # corner order of the box enumeration
+    ball = rng.normal(size=(500, 3))
+    ball = 0.05 * ball / np.linalg.norm(ball, axis=1, keepdims=True) * np.array([1.0, 2.0, 0.5])
+    pts = np.array(hull_support_points(ball))
+    assert all(any(np.array_equal(p, v) for v in ball) for p in pts)
+    lo, hi = ball.min(0), ball.max(0)
+    corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    assert np.linalg.norm(pts - corners, axis=1).min() > 0.01                 # an ellipsoid has no corners
+    octa = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float)
+    assert 1 <= len(hull_support_points(octa)) <= 6                          # duplicates are dropped
+
+
+def test_dancer_ground_points_come_from_the_reference_meshes():
+    """With the reference tree present: every ground point of the shipped Dancer model is a vertex of
+    that link's STL (in the URDF link frame); always: 8 or fewer per link, contiguous per body."""
+    import os
+    from humanoid_gym_amd.urdf import stl_vertices
+    m, _ = load_robot("dancer")
+    ground = [s for s in range(len(m.sphere_link)) if m.sphere_radius[s] == 0.0]
+    per_link = {}
+    for s in ground:
+        per_link.setdefault(int(m.sphere_link[s]), []).append(s)
+    assert len(per_link) == 18 and all(1 <= len(v) <= 8 for v in per_link.values())
+    mesh_dir = "/root/reference/humanoid_gym/envs/assets/dancer/meshes"
+    if not os.path.isdir(mesh_dir):
+        pytest.skip("reference meshes not on this machine")
+    for b, idx in per_link.items():
+        verts = stl_vertices(os.path.join(mesh_dir, m.link_names_all[b] + ".STL"))
+        assert verts is not None, m.link_names_all[b]
+        # internal (COM, principal axes) frame -> URDF link frame
+        R = quat_to_mat(m.frame_quat[b + 1])
+        for s in idx:
+            p_link = R.T @ (m.sphere_pos[s] - m.frame_pos[b + 1])
+            assert np.abs(verts - p_link).sum(1).min() < 1e-6, (m.link_names_all[b], s)
