@@ -239,7 +239,7 @@ def main():
         flops_step = algorithmic_flops_per_env_step(model, cfg, n_contacts=int(round(mean_contacts)))
         traffic = None   # HBM bytes per launch from committed PMC passes of the same kernel/config, if any
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_f_pmc_nao4096.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_g_pmc_nao4096.json")))
             if args.robot == "nao" and n_envs == 4096:
                 traffic = pm["per_launch"]["hbm_bytes_corrected"]
         except Exception:

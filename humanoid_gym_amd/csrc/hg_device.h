@@ -60,7 +60,7 @@ struct DevModel {
     float   frame_quat[HG_MAX_LINKS + 1][4];
 };
 
-enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16, F_LIMITS = 32 };
+enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16, F_LIMITS = 32, F_PRIOFLIP = 64 };
 
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;

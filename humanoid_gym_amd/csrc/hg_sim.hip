@@ -169,6 +169,7 @@ struct hg_sim {
     int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0;
     int8_t lev_start[hg::DMAX + 4]{};
     int lds_bytes = 0;
+    int n_cu = 256;             // compute units of the device (MI355X: 256)
     hg_config cfg{};
     int32_t act_joint[HG_MAX_LINKS]{};
     hg::DevModel *d_model = nullptr;
@@ -354,6 +355,16 @@ extern "C" {
 const char *hg_last_error(void) { return g_err.c_str(); }
 int hg_abi_version(void) { return 4; }
 
+#ifdef HG_PHASE_TIMING
+// diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch
+extern "C" int hg_debug_phase_ticks(unsigned long long *host_out, int n_envs) {
+    if (n_envs > HG_TICK_ENVS) n_envs = HG_TICK_ENVS;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hg::hg_ticks), sizeof(unsigned long long) * HG_TICK_SLOTS * (size_t)n_envs) != hipSuccess) return -1;
+    return HG_TICK_SLOTS;
+}
+#endif
+
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
     if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");
     *out = nullptr;
@@ -390,6 +401,7 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     hg_sim *s = new (std::nothrow) hg_sim;
     if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }
     s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) s->n_cu = cu; }
     s->n_spheres = hm->n_spheres; s->n_pairs = hm->n_pairs; s->maxlev = hm->maxlev; s->n_base_children = hm->n_base_children;
     for (int l = 0; l < DMAX + 4; l++) s->lev_start[l] = (int8_t)hm->lev_start[l];
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
@@ -466,6 +478,11 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0) |
               (c.enable_limits ? F_LIMITS : 0);
+    {   // wave-priority flip (hg_step.hip, 4b): for launches of at most one resident round; HG_PRIO_FLIP=0/1 overrides (diagnostics)
+        static const char *ov = getenv("HG_PRIO_FLIP");
+        const long resident = (long)s->n_cu * 4 * hg::kVariants[s->variant].wpe;
+        if (ov ? atoi(ov) != 0 : (long)s->n_envs <= resident) P.flags |= F_PRIOFLIP;
+    }
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];
     P.kp = (float)c.kp; P.kd = (float)c.kd; P.erp = (float)c.contact_erp; P.mu = (float)c.friction;

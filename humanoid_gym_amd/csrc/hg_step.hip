@@ -31,6 +31,22 @@
 
 namespace hg {
 
+// Diagnostics build only (-DHG_PHASE_TIMING, tools/phase_ticks.py): lane 0 of the first envs writes the
+// shader clock at every phase boundary.  The product library is built without it.
+#ifdef HG_PHASE_TIMING
+#define HG_TICK_ENVS 4096
+#define HG_TICK_SLOTS 16
+__device__ unsigned long long hg_ticks[HG_TICK_ENVS][HG_TICK_SLOTS];
+#define HG_TICK(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (threadIdx.x == 0 && blockIdx.x < HG_TICK_ENVS) hg_ticks[blockIdx.x][K] = t_; } while (0)
+// where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) in slot 13, XCC_ID in slot 14
+#define HG_TICK_HWID() do { unsigned h_, x_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(h_), "=s"(x_)); \
+        if (threadIdx.x == 0 && blockIdx.x < HG_TICK_ENVS) { hg_ticks[blockIdx.x][13] = h_; hg_ticks[blockIdx.x][14] = x_; } } while (0)
+#else
+#define HG_TICK(K) do { } while (0)
+#define HG_TICK_HWID() do { } while (0)
+#endif
+
 // The workgroup is ONE wavefront, whose LDS operations execute in program order, so lanes can
 // hand data to each other through LDS without s_barrier (which would also drain vmcnt).  What is
 // still needed is that hipcc does not move LDS accesses across the hand-off point.
@@ -41,6 +57,16 @@ HG_FI int fresh_lane() {
     int l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
+}
+
+// instruction-arbiter priority of this wave (s_setprio takes an immediate)
+HG_FI void set_prio(const int p) {
+    switch (p & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
 }
 
 HG_FI void wave_sync() {
@@ -107,6 +133,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const JcL = lds + L.AB;                        // ndof * NC3 (after the ABA is done)
     float *const accL = lds + L.acc;                      // 8 * (n+1): accelerations root -> leaves
 
+    HG_TICK(0);
+    HG_TICK_HWID();
     const bool is_link = lane < n;
     const int S = HG_STATE_SIZE(n);
     float *const st = state + (size_t)env * S;
@@ -148,6 +176,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         wave_sync();
     }
 
+    HG_TICK(1);
     int nc = 0;                       // contacts of the current physics step
     unsigned long long link_mask = 0;
 
@@ -211,6 +240,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         wave_sync();
+        HG_TICK(2);
         Sv v = v0;
         V3 gl = v3(0, 0, 0);                   // gravity in the link frame
         #pragma unroll 1
@@ -231,6 +261,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             wave_sync();
         }
 
+        HG_TICK(3);
         // ============ 2. contact detection on the current pose =================================
         nc = 0;
         link_mask = 0;
@@ -318,6 +349,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             nc = count < P.maxc ? count : P.maxc;
         }
 
+        HG_TICK(4);
         // ============ 3. articulated-body algorithm ============================================
         wave_sync();      // pub (poses, velocities) is dead: region AB now holds the child -> parent records
         // Prelude, lane = link: velocity-product acceleration and bias force.  The link's own `up`
@@ -414,6 +446,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
             }
         }
+        HG_TICK(5);
         // base (every lane computes the same thing; results stay in registers)
         Sv a0;
         {
@@ -483,6 +516,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 wave_sync();
             }
         }
+        HG_TICK(6);
         // velocities += dt * unconstrained acceleration
         // (every velocity coordinate is clamped to +-vmax after each update, as btMultiBody does)
         qd = clampv(fmaf(P.dt, qdd, qd), P.vmax);
@@ -671,6 +705,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
         wave_sync();
 
+        HG_TICK(7);
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
         // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
         // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
@@ -785,6 +820,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
 
+        HG_TICK(8);
+        // The SIMD's instruction arbiter serves its resident waves in strict order: equal user priority ->
+        // lowest wave slot first.  With one resident round (4096 NAO envs = 4 waves on every SIMD) the wave in
+        // slot 0 runs at single-wave speed and the one in slot 3 finishes 1.5x later, alone on an idle SIMD.
+        // Each wave therefore flips the order when it enters the solver here: slot 0 leads through the tree
+        // phases, slot 3 through the sweeps, the four finish within 10 % of each other, and their phases stay
+        // apart (tree sweeps of one wave under the solver of another).  Measured with tools/phase_ticks.py.
+        // Launches of several resident rounds mix their phases by themselves and lose 2 % to the flip: the host sets the flag
+        // only for launches that fit the GPU at once.
+        if (P.flags & F_PRIOFLIP) {
+            const int wslot = __builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id[1:0]: slot of this wave on its SIMD
+            set_prio((sub & 1) ? 3 - wslot : wslot);      // the next substep's tree phases keep this order, its solver flips it back
+        }
         // ---- 4b. projected Gauss-Seidel on impulses ------------------------------------------
         // Per lane j: z_j = lam_j + (b_j - w_j) / A_jj, the unclamped candidate impulse of row j
         // (w = A lam).  Updating row i by d changes z_j by -A_ji d / A_jj for j != i and leaves
@@ -964,6 +1012,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int it = 0; it + 1 < P.iters; it += 2) { sweep_limits(false); sweep_limits(true); }
             if (P.iters & 1) sweep_limits(false);
         }
+        HG_TICK(9);
         float lam = 0.f;
 #pragma unroll
         for (int k = 0; k < NROWS; k++)       // lane k <- lam_k: one v_mov under a one-lane EXEC (all 64 lanes are active here)
@@ -1053,6 +1102,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             bvel = clamp3(bvel + mulv(Rw0, ab.l), P.vmax);
         }
 
+        HG_TICK(10);
         // ============ 6. integrate positions ==================================================
         float dt = P.dt, inv_dt = P.inv_dt;
         asm volatile("" : "+s"(dt), "+s"(inv_dt));   // opaque: keeps dt-derived constants inside the loop
@@ -1090,6 +1140,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             st3(st + 7, bvel); st3(st + 10, bang);
         }
         wave_sync();      // the record is re-read by every lane (next substep, guard below)
+    HG_TICK(11);
     }  // substeps
 
     {   // epilogue, with its own lane index (the kernel-level one would otherwise stay live across the substep loop)
@@ -1164,6 +1215,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             O.base_xyyaw[3 * (size_t)env + 2] = atan2f(Rl.m[3], Rl.m[0]);
         }
     }
+    HG_TICK(12);
     }
 }
 

@@ -7,7 +7,7 @@ repo=$(pwd)
 out=$repo/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out/stats" -o bench --output-format csv -- python3 "$repo/bench.py" --no-cpu-baseline > "$out/bench_under_rocprof.log" 2>&1 || { echo "stats pass failed"; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$out/stats" -o bench --output-format csv -- python3 "$repo/bench.py" --no-cpu-baseline --stream-groups 0 > "$out/bench_under_rocprof.log" 2>&1 || { echo "stats pass failed"; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES" \
