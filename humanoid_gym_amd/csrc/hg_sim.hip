@@ -478,10 +478,12 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0) |
               (c.enable_limits ? F_LIMITS : 0);
-    {   // wave-priority flip (hg_step.hip, 4b): for launches of at most one resident round; HG_PRIO_FLIP=0/1 overrides (diagnostics)
+    {   // wave-priority flip (hg_step.hip, 4b): for launches of at most one resident round.  Diagnostics: HG_PRIO_FLIP=0 / 1
+        // forces it off / on, a value > 1 (hex) is on with that byte as the per-slot priority pattern (default 0xE4).
         static const char *ov = getenv("HG_PRIO_FLIP");
+        static const long ovv = ov ? strtol(ov, nullptr, 16) : -1;
         const long resident = (long)s->n_cu * 4 * hg::kVariants[s->variant].wpe;
-        if (ov ? atoi(ov) != 0 : (long)s->n_envs <= resident) P.flags |= F_PRIOFLIP;
+        if (ov ? ovv != 0 : (long)s->n_envs <= resident) P.flags |= F_PRIOFLIP | (int)(((ovv > 1 ? ovv : 0xE4) & 0xff) << 8);
     }
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];

@@ -831,7 +831,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // only for launches that fit the GPU at once.
         if (P.flags & F_PRIOFLIP) {
             const int wslot = __builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id[1:0]: slot of this wave on its SIMD
-            set_prio((sub & 1) ? 3 - wslot : wslot);      // the next substep's tree phases keep this order, its solver flips it back
+            // priority of slot w: bits [2w, 2w + 2) of the pattern byte in flags (0xE4 = 0, 1, 2, 3); odd substeps mirror it
+            set_prio((int)((unsigned)P.flags >> (8 + 2 * ((sub & 1) ? 3 - wslot : wslot))));      // the next substep's tree phases keep this order, its solver flips it back
         }
         // ---- 4b. projected Gauss-Seidel on impulses ------------------------------------------
         // Per lane j: z_j = lam_j + (b_j - w_j) / A_jj, the unclamped candidate impulse of row j
