@@ -337,3 +337,26 @@ def test_env_groups_on_streams_are_bit_identical_to_one_handle():
     grp.wait(); torch.cuda.synchronize()
     assert torch.equal(stats_g, stats_o) and float(stats_o[0]) == 40 * n_envs
     grp.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_wave_priority_flip_does_not_change_results():
+    """hg_step flips the waves' arbiter priorities only for launches that fit the GPU at once.  A
+    4096-env launch (flip on) and the first 4096 envs of a 4608-env launch (two rounds: flip off) must agree
+    bit for bit: scheduling is not arithmetic."""
+    import torch
+    from humanoid_gym_amd._capi import HgSim
+    from humanoid_gym_amd.robots import load_robot
+    model, cfg = load_robot("nao")
+    a, b = HgSim(model, cfg, 4096, "cuda:0"), HgSim(model, cfg, 4608, "cuda:0")
+    rng = np.random.default_rng(77)
+    idx = np.asarray(model.act_joint)
+    for t in range(12):
+        act = torch.tensor(rng.uniform(model.lower[idx], model.upper[idx], (4608, model.n_act)),
+                           dtype=torch.float32, device="cuda:0")
+        a.step(act[:4096].contiguous())
+        b.step(act)
+    torch.cuda.synchronize()
+    assert torch.equal(a.get_state(), b.get_state()[:4096])
+    assert torch.equal(a.obs_q, b.obs_q[:4096]) and torch.equal(a.collision, b.collision[:4096])
+    a.close(); b.close()
