@@ -15,7 +15,7 @@ One "step" = one hg_step launch over all envs of this rank (targets -> physics
 kernel's output stage); actions are resident in HBM before the timed region.  N > 1: one process per GPU
 (torchrun), envs sharded with no data-path collective; the only collective is
 hg_stats_flush + the RCCL all-reduce of the 8-float episode-statistics vector
-every 16 steps on a side stream.
+every 32 steps on a side stream.
 
 Prints ONE JSON line (rank 0).
 """
@@ -157,7 +157,8 @@ def main():
     phase = (torch.arange(n_envs, device=dev) + first_env) % T_TRAJ
     rows_d = torch.tensor(rows, device=dev)
     actions = torch.stack([rows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
-    stats = EpisodeStats(sim, reduce_every=16)
+    # statistics all-reduce every 32 steps on a side stream; HG_STATS_EVERY / HG_STATS_SIDE=0 (main stream) for tools/stats_cadence.sh
+    stats = EpisodeStats(sim, reduce_every=int(os.environ.get("HG_STATS_EVERY", "32")), side_stream=os.environ.get("HG_STATS_SIDE", "1") != "0")
     _dbg("sim and actions ready")
 
     def step(t):
