@@ -242,7 +242,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "round1_g_pmc_nao4096.json")))
             if args.robot == "nao" and n_envs == 4096:
-                traffic = pm["per_launch"]["hbm_bytes_corrected"]
+                traffic = pm["per_launch"].get("hbm_bytes_corrected", pm.get("hbm_bytes_corrected"))
         except Exception:
             traffic = None
         ach_gbs = n_envs * bytes_step / (kernel_ms * 1e-3) / 1e9
