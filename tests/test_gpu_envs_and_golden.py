@@ -360,3 +360,35 @@ def test_wave_priority_flip_does_not_change_results():
     assert torch.equal(a.get_state(), b.get_state()[:4096])
     assert torch.equal(a.obs_q, b.obs_q[:4096]) and torch.equal(a.collision, b.collision[:4096])
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_step_is_capturable_in_a_hip_graph():
+    """hg_step allocates nothing and never synchronises the host, so a run of steps can be
+    captured in a HIP graph and replayed: launch-bound loops (few envs) then cost one graph launch.  The replay
+    must reproduce the eager run bit for bit."""
+    import torch
+    from humanoid_gym_amd._capi import HgSim
+    from humanoid_gym_amd.robots import load_robot
+    model, cfg = load_robot("nao")
+    n_envs, K = 64, 8
+    eager, graphed = HgSim(model, cfg, n_envs, "cuda:0"), HgSim(model, cfg, n_envs, "cuda:0")
+    rng = np.random.default_rng(9)
+    idx = np.asarray(model.act_joint)
+    acts = torch.tensor(rng.uniform(model.lower[idx], model.upper[idx], (K, n_envs, model.n_act)),
+                        dtype=torch.float32, device="cuda:0")
+    static = acts.clone()
+    graphed.step(static[0]); graphed.reset()          # warm up outside the capture (lazy module load)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(K):
+            graphed.step(static[k])
+    for rep in range(3):                              # 3 x K steps, same action rows each time
+        g.replay()
+        for k in range(K):
+            eager.step(acts[k])
+    torch.cuda.synchronize()
+    assert torch.equal(eager.get_state(), graphed.get_state())
+    assert torch.equal(eager.obs_q, graphed.obs_q) and torch.equal(eager.done, graphed.done)
+    eager.close(); graphed.close()
