@@ -26,6 +26,9 @@
 //     sweep (w = J dv), same iterates, no reductions; violated joint limits ride
 //     along as extra rows on the wave's spare lanes;
 //   * the final M^-1 J^T lambda is one more level-by-level ABA response.
+// Scheduling: one wave per workgroup (a workgroup of several envs keeps its LDS until its slowest wave ends:
+// measured slower); launches that fit the GPU at once reverse the SIMD arbiter's service order of their
+// waves at solver entry with s_setprio (see 4b), so that the waves of a SIMD finish together.
 #include "hg_device.h"
 #include "hg_math.h"
 
