@@ -64,6 +64,7 @@ enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16, F_L
 
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
+    int32_t flip_from;    // envs >= flip_from flip their wave priority at solver entry (F_PRIOFLIP)
     // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
     int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children;
     int8_t  lev_start[DMAX + 4];

@@ -478,12 +478,15 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0) |
               (c.enable_limits ? F_LIMITS : 0);
-    {   // wave-priority flip (hg_step.hip, 4b): for launches of at most one resident round.  Diagnostics: HG_PRIO_FLIP=0 / 1
-        // forces it off / on, a value > 1 (hex) is on with that byte as the per-slot priority pattern (default 0xE4).
+    {   // Wave-priority flip (hg_step.hip, 4b): every env of a launch that fits the GPU at once; of a longer launch only the
+        // last half resident round (the tail is where waves are left alone on their SIMD; in the middle of the launch the
+        // phases mix by themselves and the flip costs 2 %).  Diagnostics: HG_PRIO_FLIP=0 never, 1 every env, a value > 1
+        // (hex) every env with that byte as the per-slot priority pattern (default 0xE4).
         static const char *ov = getenv("HG_PRIO_FLIP");
         static const long ovv = ov ? strtol(ov, nullptr, 16) : -1;
         const long resident = (long)s->n_cu * 4 * hg::kVariants[s->variant].wpe;
-        if (ov ? ovv != 0 : (long)s->n_envs <= resident) P.flags |= F_PRIOFLIP | (int)(((ovv > 1 ? ovv : 0xE4) & 0xff) << 8);
+        P.flip_from = (!ov && (long)s->n_envs > resident) ? (int)(s->n_envs - resident / 2) : 0;
+        if (!ov || ovv != 0) P.flags |= F_PRIOFLIP | (int)(((ovv > 1 ? ovv : 0xE4) & 0xff) << 8);
     }
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);
     P.gx = (float)c.gravity[0]; P.gy = (float)c.gravity[1]; P.gz = (float)c.gravity[2];

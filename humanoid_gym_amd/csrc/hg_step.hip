@@ -830,9 +830,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // Each wave therefore flips the order when it enters the solver here: slot 0 leads through the tree
         // phases, slot 3 through the sweeps, the four finish within 10 % of each other, and their phases stay
         // apart (tree sweeps of one wave under the solver of another).  Measured with tools/phase_ticks.py.
-        // Launches of several resident rounds mix their phases by themselves and lose 2 % to the flip: the host sets the flag
-        // only for launches that fit the GPU at once.
-        if (P.flags & F_PRIOFLIP) {
+        // Launches of several resident rounds mix their phases by themselves and lose 2 % to the flip, but their tail has the
+        // same problem: the host sets flip_from to 0 for launches that fit the GPU at once and to the last half round otherwise.
+        if ((P.flags & F_PRIOFLIP) && env >= P.flip_from) {
             const int wslot = __builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id[1:0]: slot of this wave on its SIMD
             // priority of slot w: bits [2w, 2w + 2) of the pattern byte in flags (0xE4 = 0, 1, 2, 3); odd substeps mirror it
             set_prio((int)((unsigned)P.flags >> (8 + 2 * ((sub & 1) ? 3 - wslot : wslot))));      // the next substep's tree phases keep this order, its solver flips it back
