@@ -14,7 +14,8 @@ import numpy as np
 
 from .model import FlatModel, HgConfig, HgModel, SimConfig, HG_MAX_CONTACTS, HG_STATE_BASE
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhg_sim.so")
+# HG_SIM_LIB: another build of the same library (diagnostics: tools/phase_ticks.py, compiler-flag comparisons)
+_LIB_PATH = os.environ.get("HG_SIM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhg_sim.so")
 _lib = None
 
 SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_reset", "hg_step",
