@@ -99,6 +99,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     constexpr int NC3 = 3 * MAXC;
     constexpr int NROWS = NMX + NC3;
     static_assert(NROWS <= WAVE, "rows must fit one wavefront");
+    static_assert((6 * NC3) % 4 == 0, "the joint part of Jc must start on a 16-byte boundary (even MAXC)");
 
     extern __shared__ __align__(16) float lds[];
     const int env = blockIdx.x;
@@ -594,7 +595,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 float zero = 0.f;
                 asm volatile("" : "+v"(zero));       // materialised here: a hoisted zero quad would be spilled
                 #pragma unroll 1
-                for (int k = lane; k < (n * NC3) / 4; k += WAVE) z4[k] = make_float4(zero, zero, zero, zero);
+                // whole quads, rounded UP: (n * NC3) % 4 may be 2 (odd n with NC3 = 18); 6 * NC3 is a multiple of 4 and the
+                // region is sized rup4((6 + n) * NC3), so the last quad stays inside it
+                for (int k = lane; k < (n * NC3 + 3) / 4; k += WAVE) z4[k] = make_float4(zero, zero, zero, zero);
             }
             wave_sync();
             // ... except on the path(s) from the contact bodies to the base: at most DEPTH entries per column

@@ -18,8 +18,10 @@ from .base import BatchedHumanoidEnv
 
 
 class DancerEnv(BatchedHumanoidEnv):
-    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, self_collision: bool = False,
+    def __init__(self, n_envs: int = 1, device=None, urdf_path=None, self_collision: bool = True,
                  n_substeps: int = 1, auto_reset: bool = False, **cfg_overrides):
+        """self_collision=True is the reference's only mode (loadURDF flags, dancer_env.py:60): `collision` and
+        the contact pairs then include link-link contacts (dancer_env.py:33-39); False is an opt-out."""
         model, cfg = load_robot("dancer", urdf_path)
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)

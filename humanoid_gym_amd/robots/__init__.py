@@ -33,16 +33,20 @@ PEPPER_JOINTS = ['LShoulderPitch', 'LShoulderRoll', 'LElbowYaw', 'LElbowRoll', '
 
 
 def dancer_config(**kw) -> SimConfig:
-    # dancer_env.py:63-65; setJointMotorControlArray does not clamp targets
-    c = SimConfig(gravity=(0.0, 0.0, -10.0), solver_iters=150, max_contacts=12, clamp_targets=False)
+    # dancer_env.py:63-65; setJointMotorControlArray does not clamp targets; loadURDF is called with
+    # URDF_USE_SELF_COLLISION + URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS (dancer_env.py:60)
+    c = SimConfig(gravity=(0.0, 0.0, -10.0), solver_iters=150, max_contacts=12, clamp_targets=False,
+                  enable_self=True)
     for k, v in kw.items():
         setattr(c, k, v)
     return c
 
 
 def softbank_config(**kw) -> SimConfig:
-    # PyBullet defaults under qibullet; setAngles clamps to the joint limits
-    c = SimConfig(gravity=(0.0, 0.0, -9.81), solver_iters=50, max_contacts=8, clamp_targets=True)
+    # PyBullet defaults under qibullet; setAngles clamps to the joint limits; qibullet loads its robots
+    # with URDF_USE_SELF_COLLISION [UPSTREAM-RECALL], so link-link contacts are on here as well
+    c = SimConfig(gravity=(0.0, 0.0, -9.81), solver_iters=50, max_contacts=8, clamp_targets=True,
+                  enable_self=True)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

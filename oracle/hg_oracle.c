@@ -815,6 +815,51 @@ void hgo_energy_momentum(const hg_model *m, const hg_config *c, const double *st
     }
 }
 
+/*
+ * How close the contact SET of one env's pose is to changing (tests/test_gpu_parity.py: the integer
+ * outputs of the FP32 kernel may differ from this restatement's only where this is within FP32
+ * rounding of a position).  out[0]: smallest |distance - contact_margin| over all ground-tested spheres
+ * and (with enable_self) all candidate sphere pairs; out[1]: smallest gap between the 4th and the
+ * 5th smallest in-margin distance of one body (the "4 deepest per body" rule flips there); 1e30 when
+ * there is no such candidate.
+ */
+void hgo_contact_slack(const hg_model *m, const hg_config *c, const double *state, double *out2) {
+    static _Thread_local scratch_t W;
+    double cw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
+    kinematics(m, state, &W);
+    out2[0] = 1e30; out2[1] = 1e30;
+    for (int s = 0; s < m->n_spheres; s++) {
+        const int b = m->sphere_link[s] + 1;
+        double t[3];
+        m3_mulv(W.Rw[b], m->sphere_pos[s], t);
+        for (int k = 0; k < 3; k++) cw[s][k] = W.xw[b][k] + t[k];
+        dist[s] = cw[s][2] - m->sphere_radius[s];
+        if (c->enable_ground && (m->sphere_flags[s] & 1)) {
+            const double g = fabs(dist[s] - c->contact_margin);
+            if (g < out2[0]) out2[0] = g;
+        }
+    }
+    if (c->enable_ground)
+        for (int s = 0; s < m->n_spheres; s++) {
+            if (!(m->sphere_flags[s] & 1) || !(dist[s] < c->contact_margin)) continue;
+            /* in-margin distances of this sphere's body, sorted: gap between ranks 3 and 4 (0-based) */
+            double d[HG_MAX_SPHERES]; int k = 0;
+            for (int o = 0; o < m->n_spheres; o++)
+                if (m->sphere_link[o] == m->sphere_link[s] && (m->sphere_flags[o] & 1) && dist[o] < c->contact_margin) d[k++] = dist[o];
+            if (k <= 4) continue;
+            for (int i = 1; i < k; i++) { double v = d[i]; int j = i - 1; while (j >= 0 && d[j] > v) { d[j + 1] = d[j]; j--; } d[j + 1] = v; }
+            if (d[4] - d[3] < out2[1]) out2[1] = d[4] - d[3];
+        }
+    if (c->enable_self)
+        for (int p = 0; p < m->n_pairs; p++) {
+            const int a = m->pair_a[p], b = m->pair_b[p];
+            double dd[3] = {cw[a][0] - cw[b][0], cw[a][1] - cw[b][1], cw[a][2] - cw[b][2]};
+            const double ds = sqrt(v3_dot(dd, dd)) - m->sphere_radius[a] - m->sphere_radius[b];
+            const double g = fabs(ds - c->contact_margin);
+            if (g < out2[0]) out2[0] = g;
+        }
+}
+
 /* world-frame pose of every body, for kinematics checks: Rw[(n+1)*9], xw[(n+1)*3] */
 void hgo_kinematics(const hg_model *m, const double *state, double *Rw, double *xw) {
     static _Thread_local scratch_t W;

@@ -56,6 +56,8 @@ def lib():
         L.hgo_apply_minv.restype = C.c_int
         L.hgo_energy_momentum.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp]
         L.hgo_energy_momentum.restype = None
+        L.hgo_contact_slack.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp]
+        L.hgo_contact_slack.restype = None
         L.hgo_kinematics.argtypes = [C.POINTER(HgModel), dp, dp, dp]
         L.hgo_kinematics.restype = None
         _LIB = L
@@ -153,6 +155,14 @@ class OracleSim:
         st = np.ascontiguousarray(self.state[env])
         lib().hgo_energy_momentum(C.byref(self.cm), C.byref(self.cc), _dp(st), _dp(out))
         return dict(kinetic=out[0], potential=out[1], p=out[2:5].copy(), L=out[5:8].copy())
+
+    def contact_slack(self, env=0):
+        """(smallest |distance - margin| of any contact candidate, smallest 4th/5th-deepest gap of a body)
+        for the CURRENT pose of one env: how far its contact set is from changing."""
+        out = np.zeros(2)
+        st = np.ascontiguousarray(self.state[env])
+        lib().hgo_contact_slack(C.byref(self.cm), C.byref(self.cc), _dp(st), _dp(out))
+        return float(out[0]), float(out[1])
 
     def kinematics(self, env=0):
         Rw, xw = np.zeros((self.n + 1, 3, 3)), np.zeros((self.n + 1, 3))

@@ -29,9 +29,9 @@ def run(name, n_envs, steps, seed, **kw):
           f"worst q err: median {np.median(worst):.2e} max {worst.max():.2e}", flush=True)
 
 
-run("dancer", 8, 240, 1, enable_ground=False, gravity=(0.0, 0.0, 0.0))
+run("dancer", 8, 240, 1, enable_ground=False, enable_self=False, gravity=(0.0, 0.0, 0.0))
 run("dancer", 8, 120, 2)
-run("nao", 8, 240, 3, enable_ground=False)
+run("nao", 8, 240, 3, enable_ground=False, enable_self=False)
 run("nao", 8, 240, 4)
 run("pepper", 4, 120, 5)
 run("romeo", 4, 120, 6)

@@ -23,7 +23,7 @@ def _sim(name, n_envs, **kw):
 
 def test_golden_nao_replay_free_1e4():
     z = np.load(os.path.join(HERE, "golden", "oracle_nao_replay_free.npz"))
-    model, cfg, sim, torch = _sim("nao", 2, enable_ground=False, gravity=(0.0, 0.0, 0.0))
+    model, cfg, sim, torch = _sim("nao", 2, enable_ground=False, enable_self=False, gravity=(0.0, 0.0, 0.0))
     worst = 0.0
     for t in range(240):
         act = torch.tensor(z["rows"][(t + np.array([0, 37])) % 240], device="cuda:0")
@@ -70,7 +70,8 @@ def test_dancer_env_single_env_reference_semantics():
     assert env.reset() is None and env.step_counter == 0
     obs, reward, done, info = env.step(env.action_space.sample())
     assert isinstance(obs, list) and len(obs) == 18 and reward == 0 and done is False
-    assert info == {"collision": False} and env.step_counter == 1
+    # reference flags (dancer_env.py:60): link-link contacts count, and at q = 0 the feet already touch each other
+    assert set(info) == {"collision"} and isinstance(info["collision"], bool) and env.step_counter == 1
     seen = {}
 
     def custom(jointStates, linkStates, collision, step_counter):        # dancer_env.py:49
@@ -86,8 +87,16 @@ def test_dancer_env_single_env_reference_semantics():
     assert set(seen["ls"]) == set(env.link_names) and len(seen["ls"]["foot2_left"]) == 6
     assert info["collision"] is True and seen["col"] is True              # standing on the ground by now
     pairs, counts = env.contact_pairs()
-    assert counts[0].item() == 8
+    p0 = pairs[0, :counts[0].item()].cpu().numpy()
+    assert int((p0[:, 1] == -2).sum()) == 8                                # 2 x 4 foot corners on the ground
+    assert int((p0[:, 1] >= 0).sum()) >= 1                                 # and the foot-foot contact (dancer_env.py:36-37)
     env.close()
+    off = hg.make("dancer-v0", self_collision=False)                       # opt-out: ground contacts only
+    for _ in range(40):
+        off.step([0.0] * 18)
+    pairs, counts = off.contact_pairs()
+    assert counts[0].item() == 8 and bool((pairs[0, :8, 1] == -2).all())
+    off.close()
 
 
 def test_nao_pepper_romeo_env_surfaces():

@@ -48,7 +48,7 @@ def test_aba_matches_mass_matrix(name, tmp_path):
     else:
         model, cfg = load_robot(name)
     cfg.lin_damping = cfg.ang_damping = 0.0
-    cfg.enable_ground = False
+    cfg.enable_ground = False; cfg.enable_self = False
     sim = OracleSim(model, cfg, 1)
     rng = np.random.default_rng(0)
     n = model.n_links
@@ -99,6 +99,7 @@ def test_energy_and_momentum_drift_is_first_order():
 
 def test_dancer_falls_35mm_then_stands_on_eight_corners():
     model, cfg = load_robot("dancer")
+    cfg.enable_self = False                       # the ground-only statement; the reference's flags are the next test
     sim = OracleSim(model, cfg, 1)
     z0 = sim.state[0, 2]
     first = None
@@ -114,9 +115,27 @@ def test_dancer_falls_35mm_then_stands_on_eight_corners():
     assert np.abs(sim.q[0]).max() < 2e-3 and np.abs(sim.qd[0]).max() < 1e-2
 
 
+def test_dancer_reference_flags_add_foot_foot_contacts():
+    """dancer_env.py:60 loads with URDF_USE_SELF_COLLISION (+ EXCLUDE_ALL_PARENTS), the default config here:
+    at q = 0 the feet touch each other, so link-link pairs (11, 17) ride along with the 8 ground points and
+    `collision` is raised from the first step (dancer_env.py:33-39)."""
+    model, cfg = load_robot("dancer")
+    assert cfg.enable_self
+    sim = OracleSim(model, cfg, 1)
+    o = sim.step(np.zeros((1, 18)))
+    assert o["collision"][0] == 1 and o["n_contacts"][0] >= 1 and (o["pairs"][0, :o["n_contacts"][0], 1] >= 0).all()
+    for t in range(239):
+        o = sim.step(np.zeros((1, 18)))
+    p = o["pairs"][0, :o["n_contacts"][0]]
+    assert int((p[:, 1] == -2).sum()) == 8 and set(p[p[:, 1] == -2, 0].tolist()) == {11, 17}
+    assert {tuple(x) for x in p[p[:, 1] >= 0].tolist()} == {(11, 17)}
+    assert int(o["link_mask"][0]) == (1 << 12) | (1 << 18)
+    assert np.isfinite(sim.state).all() and np.abs(sim.qd[0]).max() < 5e-2
+
+
 def test_position_motor_tracks_target_contact_free():
     model, cfg = load_robot("nao")
-    cfg.enable_ground = False; cfg.gravity = (0.0, 0.0, 0.0)
+    cfg.enable_ground = False; cfg.enable_self = False; cfg.gravity = (0.0, 0.0, 0.0)
     sim = OracleSim(model, cfg, 1)
     tgt = np.clip(model.q_init[np.asarray(model.act_joint)] + 0.2, model.lower[model.act_joint], model.upper[model.act_joint])
     for _ in range(240):
@@ -141,7 +160,7 @@ def test_oracle_reproduces_committed_trajectories(fixture):
     else:
         model, cfg = load_robot("nao")
         if fixture.endswith("free"):
-            cfg.enable_ground = False; cfg.gravity = (0.0, 0.0, 0.0)
+            cfg.enable_ground = False; cfg.enable_self = False; cfg.gravity = (0.0, 0.0, 0.0)
         sim = OracleSim(model, cfg, 2)
         for t in range(240):
             o = sim.step(z["rows"][(t + np.array([0, 37])) % 240], joint_sel=z["sel"])
@@ -204,7 +223,7 @@ def test_motor_torque_is_the_impulse_that_moved_the_robot(name):
     step must be M^-1 applied to the generalized impulse (0 on the base, motor torque * dt on the joints),
     and no motor may exceed its force limit."""
     model, cfg = load_robot(name)
-    cfg.enable_ground = False; cfg.gravity = (0.0, 0.0, 0.0); cfg.enable_limits = False
+    cfg.enable_ground = False; cfg.enable_self = False; cfg.gravity = (0.0, 0.0, 0.0); cfg.enable_limits = False
     sim = OracleSim(model, cfg, 1)
     n = model.n_links
     rng = np.random.default_rng(8)

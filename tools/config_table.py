@@ -33,9 +33,12 @@ def run(name, n_envs, n_substeps=1, reps=30, seed=0, **kw):
     sim.close()
 
 if __name__ == "__main__":
+    # the defaults have ground AND link-link contacts on (dancer_env.py:60; BASELINE config 4); the
+    # enable_self=False rows are there to show what the pair table costs
     run("nao", 4096, seed=0)
+    run("nao", 4096, seed=0, enable_self=False)
     run("pepper", 16384, seed=2)
     run("romeo", 8192, seed=3)
-    run("romeo", 8192, seed=3, enable_self=False, max_contacts=4)
+    run("romeo", 8192, seed=3, enable_self=False)
     run("dancer", 65536, n_substeps=4, seed=4)
-    run("dancer", 65536, n_substeps=4, seed=4, enable_self=True)
+    run("dancer", 65536, n_substeps=4, seed=4, enable_self=False)
