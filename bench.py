@@ -12,10 +12,11 @@ PD position control + ground contact on, 1 physics substep (1/240 s) per step.
 
 One "step" = one hg_step launch over all envs of this rank (targets -> physics
 -> observations, with the per-env episode-statistics accumulation fused into the
-kernel's output stage); actions are resident in HBM before the timed region.  N > 1: one process per GPU
-(torchrun), envs sharded with no data-path collective; the only collective is
-hg_stats_flush + the RCCL all-reduce of the 8-float episode-statistics vector
-every 32 steps on a side stream.
+kernel's output stage); actions are resident in HBM before the timed region.  N > 1: one process per GPU,
+envs sharded with no data-path collective; the only collective is hg_stats_flush + the RCCL all-reduce of
+the 8-float episode-statistics vector every 32 steps on a side stream.  `python bench.py --gpus N` with no
+RANK in the environment starts the N ranks itself (a child `python -m torch.distributed.run`, the parent
+never touches a GPU) and relays rank 0's line; under an outer torchrun it is one of the ranks.
 
 Prints ONE JSON line (rank 0).
 """
@@ -81,17 +82,54 @@ def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
     c0 = time.perf_counter(); run(steps, 8); dt = time.perf_counter() - c0
     out = {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
            "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
-    # single thread beside it: one env, the oracle takes its serial path below four envs
+    # single thread beside it = BASELINE.json configs[0] (SURVEY 8d "Config 1"): nao-v0, ONE env, random_control
+    # (random_control_nao.py:9: action_space.sample() each step = U(lower_j, upper_j), default_rng(0)), 1000 steps;
+    # the oracle takes its serial path below four envs
     one = OracleSim(model, cfg, 1)
-    k = int(max(50, min(4000, 3.0 / max(per * threads / n_envs, 1e-7))))
-    for t in range(8):
-        one.step(rows[t % T_TRAJ][None], joint_sel=sel)
+    idx = np.asarray(model.act_joint)
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(model.lower[idx], model.upper[idx], (1000, 1, len(idx)))
     c0 = time.perf_counter()
-    for t in range(k):
-        one.step(rows[(8 + t) % T_TRAJ][None], joint_sel=sel)
-    out["single_thread"] = {"value": k / (time.perf_counter() - c0), "unit": "env-steps/s",
-                            "sample": f"1 env x {k} steps, includes the ctypes call per step"}
+    for t in range(1000):
+        one.step(acts[t])
+    out["single_thread"] = {"value": 1000 / (time.perf_counter() - c0), "unit": "env-steps/s",
+                            "sample": "BASELINE configs[0]: nao, 1 env x 1000 random_control steps, oracle FP64, "
+                                      "includes the ctypes call per step"}
     return out
+
+
+def launch_ranks(argv, n):
+    """--gpus N without a launcher around us: start N ranks as a child torchrun and relay its output.
+    This process has not initialised HIP (no exec after GPU init: the ranks are CHILD processes)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+class DrySim:
+    """--dry-sim: stands in for HgSim so that the launcher, the sharding and the statistics all-reduce can be
+    rehearsed on CPU ranks (gloo); it simulates nothing and its line says so."""
+
+    def __init__(self, model, n_envs, device):
+        import torch
+        self.device, self.n_envs, self.n_act = torch.device(device), n_envs, model.n_act
+        self.reward = torch.zeros(n_envs); self.done = torch.zeros(n_envs, dtype=torch.uint8)
+        self.collision = torch.ones(n_envs, dtype=torch.uint8)
+        self._steps = 0
+
+    def step(self, actions=None, joint_sel=None, n_substeps=1):
+        self._steps += 1
+
+    def stats_flush(self, stats):
+        stats[0] += self._steps * self.n_envs; stats[3] += self._steps * self.n_envs
+        self._steps = 0
+        return stats
 
 
 def _dbg(msg):
@@ -112,15 +150,20 @@ def main():
     ap.add_argument("--stream-groups", type=int, default=2,
                     help="env groups of the extra `pipelined` measurement (0 = skip it); `value` is always one launch per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse")
+    ap.add_argument("--dry-sim", action="store_true",
+                    help="CPU rehearsal of the N > 1 path (launcher, sharding, statistics all-reduce) without a GPU: "
+                         "no simulation, the line is labelled and is not a measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
     if os.environ.get("HG_BENCH_DEBUG"):     # where does a stuck rank sit?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["HG_BENCH_DEBUG"]), exit=True)
 
+    import ast
     import torch
     import torch.distributed as dist
     from humanoid_gym_amd.robots import load_robot
-    from humanoid_gym_amd._capi import HgSim
     from humanoid_gym_amd.stats import EpisodeStats
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,21 +172,27 @@ def main():
     if os.environ.get("HG_BENCH_SINGLE_DEVICE"):     # rehearsal of the N > 1 path on a one-GPU box
         local_rank = 0
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # torchrun, any N
+    dry = args.dry_sim
+    if dry:
+        args.backend = "gloo"
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
+        if not dry:
+            torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    if not dry:
+        torch.cuda.set_device(dev)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     _dbg("process group ready")
 
     model, cfg = load_robot(args.robot)
     for kv in args.cfg:
         k, v = kv.split("=", 1)
-        setattr(cfg, k, type(getattr(cfg, k))(eval(v)))
+        setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
     n_envs = args.envs_per_gpu
     if args.robot == "nao":
         rows, sel = synthetic_replay(model)
@@ -151,7 +200,11 @@ def main():
         rng = np.random.default_rng(2)
         sel = np.asarray(model.act_joint, np.int32)
         rows = rng.uniform(model.lower[sel], model.upper[sel], (T_TRAJ, len(sel))).astype(np.float32)
-    sim = HgSim(model, cfg, n_envs, dev)
+    if dry:
+        sim = DrySim(model, n_envs, dev)
+    else:
+        from humanoid_gym_amd._capi import HgSim
+        sim = HgSim(model, cfg, n_envs, dev)
     # actions for every (time, env) resident in HBM: [T, n_envs, n_sel]
     first_env = rank * n_envs
     phase = (torch.arange(n_envs, device=dev) + first_env) % T_TRAJ
@@ -168,25 +221,46 @@ def main():
     for t in range(args.warmup):
         step(t)
     stats.flush()          # one statistics all-reduce outside the timed region (RCCL sets up its channels lazily)
-    torch.cuda.synchronize()
+    sync()
     _dbg("warmup done")
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for t in range(args.warmup, args.warmup + args.steps):
         step(t)
     stats.flush()
-    torch.cuda.synchronize()
+    sync()
+    own = time.perf_counter() - t0          # this rank's own work, before it waits for the others
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     _dbg("timed region done")
+    per_rank_ms = [own / args.steps * 1e3]
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        mine = torch.tensor([own / args.steps * 1e3], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_ms = [float(g.item()) for g in gathered]
+    global_env_steps = float(stats.total[0].item())      # all-reduced: every rank's envs x (warmup + steps)
+
+    if dry:
+        if rank == 0:
+            print(json.dumps({"metric": "DRY RUN (no simulation): launcher / sharding / all-reduce rehearsal", "value": 0.0,
+                              "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "none", "data": "none", "backend": args.backend,
+                              "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms)},
+                              "global_env_steps": global_env_steps,
+                              "config": {"workload": "dry", "envs_per_gpu": n_envs, "first_env_of_rank0": first_env}}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # the step kernel alone, HIP events on the stream it is launched on
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -238,13 +312,18 @@ def main():
         value = total_envs * args.steps / elapsed
         bytes_step = algorithmic_bytes_per_env_step(model, len(sel))
         flops_step = algorithmic_flops_per_env_step(model, cfg, n_contacts=int(round(mean_contacts)))
-        traffic = None   # HBM bytes per launch from committed PMC passes of the same kernel/config, if any
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_g_pmc_nao4096.json")))
-            if args.robot == "nao" and n_envs == 4096:
-                traffic = pm["per_launch"].get("hbm_bytes_corrected", pm.get("hbm_bytes_corrected"))
-        except Exception:
-            traffic = None
+        # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure is the one
+        # of the committed rocprofv3 --pmc passes over this same kernel and configuration (named in traffic_source)
+        traffic, traffic_source = None, None
+        for cand in ("round2_pmc_nao4096.json", "round1_g_pmc_nao4096.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if args.robot == "nao" and n_envs == 4096 and not args.cfg:
+                    traffic = pm["per_launch"].get("hbm_bytes_corrected", pm.get("hbm_bytes_corrected"))
+                    traffic_source = f"profiles/{cand} (rocprofv3 --pmc passes of this kernel and config, not this run)"
+                    break
+            except Exception:
+                continue
         ach_gbs = n_envs * bytes_step / (kernel_ms * 1e-3) / 1e9
         ach_tf = n_envs * flops_step / (kernel_ms * 1e-3) / 1e12
         out = {
@@ -252,14 +331,16 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms)},
+            "global_env_steps": global_env_steps,
             "config": {"workload": "NAO h5 joint-trajectory replay (h5_control_nao layout, synthetic sinusoid "
-                                   "trajectory), PD position control + ground contact, 1 substep of 1/240 s"
+                                   "trajectory), PD position control + ground contact" + (" + link-link contacts" if cfg.enable_self else "") + ", 1 substep of 1/240 s"
                        if args.robot == "nao" else f"{args.robot} random targets",
                        "robot": model.name + ("_like (stand-in URDF)" if args.robot != "dancer" else ""),
                        "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters,
                        "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hg_step_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "metric asks for the HBM fraction; the kernel is FP32-VALU bound, see `valu`"},

@@ -27,7 +27,7 @@ enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTI
 enum { B_MASS = 0, B_INERTIA = 1, B_POS0 = 4, B_QUAT0 = 7, B_FPOS = 11, B_FQUAT = 14 };
 
 struct DevModel {
-    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children, n_slots, pad0;
+    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children, n_slots, n_self;
     int8_t  parent[HG_MAX_LINKS];
     int8_t  level[HG_MAX_LINKS];        // depth, base children = 1
     int8_t  first_child[HG_MAX_LINKS];
@@ -45,7 +45,8 @@ struct DevModel {
     int8_t   lev_order[HG_MAX_LINKS];   // link indices sorted by level
     uint32_t pathw[HG_MAX_LINKS][4];    // byte d-1 of the 16: path[b][d-1] + 1 (0 = none)
     uint32_t sphere_meta[HG_MAX_SPHERES]; // (link + 1) | flags << 8 | grp_begin << 16 | grp_end << 24
-    uint32_t pair_meta[HG_MAX_PAIRS];     // sphere a | sphere b << 8 | (link a + 1) << 16 | (link b + 1) << 24
+    uint32_t pair_meta[HG_MAX_PAIRS];     // self index a | self index b << 8 | (link a + 1) << 16 | (link b + 1) << 24
+    uint8_t  self_idx[HG_MAX_SPHERES];    // compact index of a sphere among those that take part in self-collision pairs
     unsigned long long anc_mask[HG_MAX_LINKS];  // bit j: j is b or an ancestor of b
     float   link[HG_MAX_LINKS][LINKC];
     float   base[32];
@@ -66,7 +67,7 @@ struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
     int32_t flip_from;    // envs >= flip_from flip their wave priority at solver entry (F_PRIOFLIP)
     // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
-    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children;
+    int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children, n_self;
     int8_t  lev_start[DMAX + 4];
     float   dt, inv_dt, gx, gy, gz, kp, kd, erp, mu, margin, lin_damp, ang_damp, vmax, limhi;
     int8_t  sel[HG_MAX_LINKS];
@@ -88,9 +89,12 @@ struct StepOut {
 struct LdsPlan {
     int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, AB, acc, total;
 };
+// With self-collision two more arrays exist, never live together, so they share one region: the world centres
+// (+ radius) of the n_self spheres that appear in pairs (contact detection), and the second-path Y values of
+// two-body rows, kept for the contact-row lanes only (maxlev x nc3, phase 4a).
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, bool self) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
@@ -100,9 +104,8 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
     p.lam = o;   p.misc = o; o += 64;
     p.con = o;   o += CON * (nc3 / 3);
-    p.Yd2 = o;   o += self ? maxlev * WAVE : 0;
+    p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
     p.sdist = o; o += rup4(ns);
-    p.scen = o;  o += self ? 4 * ns : 0;
     p.tab = o;   o += rup4(4 * n);          // int tables: next_sibling, base_children, first_child, lev_order
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);

@@ -166,7 +166,7 @@ struct hg_sim {
     int device = 0;
     int n_envs = 0, n = 0, n_act = 0, state_size = 0;
     int variant = 0;            // index into the (NMX, MAXC) instantiation table
-    int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0;
+    int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0, n_self = 0;
     int8_t lev_start[hg::DMAX + 4]{};
     int lds_bytes = 0;
     int n_cu = 256;             // compute units of the device (MI355X: 256)
@@ -319,17 +319,26 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
             if (m->sphere_link[o] == m->sphere_link[s]) { *why = "collision spheres of one body must be contiguous"; return HG_EINVAL; }
         for (int k = s; k < e; k++) {
             D->grp_begin[k] = (int16_t)s; D->grp_end[k] = (int16_t)e;
-            D->sphere_meta[k] = (uint32_t)(uint8_t)(m->sphere_link[k] + 1) | ((uint32_t)(m->sphere_flags[k] & 0xff) << 8) |
+            D->sphere_meta[k] = (uint32_t)(uint8_t)(m->sphere_link[k] + 1) | ((uint32_t)(m->sphere_flags[k] & 0x3) << 8) |
                                 ((uint32_t)s << 16) | ((uint32_t)e << 24);
         }
         s = e;
     }
+    // spheres that appear in some pair get a compact index: only their world centres are kept in LDS
+    int self_of[HG_MAX_SPHERES], n_self = 0;
+    for (int s = 0; s < m->n_spheres; s++) self_of[s] = -1;
     for (int k = 0; k < m->n_pairs; k++) {
         if (m->pair_a[k] < 0 || m->pair_a[k] >= m->n_spheres || m->pair_b[k] < 0 || m->pair_b[k] >= m->n_spheres) {
             *why = "self-collision pair out of range"; return HG_EINVAL;
         }
+        self_of[m->pair_a[k]] = self_of[m->pair_b[k]] = 0;
+    }
+    for (int s = 0; s < m->n_spheres; s++)
+        if (self_of[s] == 0) { self_of[s] = n_self; D->self_idx[s] = (uint8_t)n_self; n_self++; D->sphere_flags[s] |= 0x80; D->sphere_meta[s] |= 0x8000u; }
+    D->n_self = c->enable_self ? n_self : 0;
+    for (int k = 0; k < m->n_pairs; k++) {
         D->pair_a[k] = (int16_t)m->pair_a[k]; D->pair_b[k] = (int16_t)m->pair_b[k];
-        D->pair_meta[k] = (uint32_t)m->pair_a[k] | ((uint32_t)m->pair_b[k] << 8) |
+        D->pair_meta[k] = (uint32_t)self_of[m->pair_a[k]] | ((uint32_t)self_of[m->pair_b[k]] << 8) |
                           ((uint32_t)(uint8_t)(m->sphere_link[m->pair_a[k]] + 1) << 16) |
                           ((uint32_t)(uint8_t)(m->sphere_link[m->pair_b[k]] + 1) << 24);
     }
@@ -403,10 +412,11 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->device = device_id; s->n_envs = n_envs; s->n = n; s->n_act = model->n_act;
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) s->n_cu = cu; }
     s->n_spheres = hm->n_spheres; s->n_pairs = hm->n_pairs; s->maxlev = hm->maxlev; s->n_base_children = hm->n_base_children;
+    s->n_self = hm->n_self;
     for (int l = 0; l < DMAX + 4; l++) s->lev_start[l] = (int8_t)hm->lev_start[l];
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
-    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, config->enable_self != 0).total;
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_size);
@@ -473,7 +483,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     P.n_envs = s->n_envs; P.n_substeps = n_substeps; P.iters = c.solver_iters; P.maxc = c.max_contacts;
     P.n_sel = n_sel;
     P.n = s->n; P.n_spheres = s->n_spheres; P.n_pairs = s->n_pairs; P.n_act = s->n_act; P.maxlev = s->maxlev;
-    P.n_base_children = s->n_base_children;
+    P.n_base_children = s->n_base_children; P.n_self = s->n_self;
     memcpy(P.lev_start, s->lev_start, sizeof P.lev_start);
     P.flags = (c.enable_ground ? F_GROUND : 0) | (c.enable_self ? F_SELF : 0) | (c.clamp_targets ? F_CLAMP : 0) |
               ((actions_dev && n_sel > 0) ? F_ACTIONS : 0) | (s->base_cmd_on ? F_BASECMD : 0) |

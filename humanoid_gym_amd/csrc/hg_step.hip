@@ -109,7 +109,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = P.n_spheres;
     const int maxlev = P.maxlev;
-    LdsPlan L = lds_plan(n, ns, NC3, maxlev, (P.flags & F_SELF) != 0);
+    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self);
     // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
     // leave them in VGPRs that stay live for the whole kernel)
     L.AB = __builtin_amdgcn_readfirstlane(L.AB);
@@ -124,8 +124,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const miscL = lds + L.misc;
     float *const conL = lds + L.con;
     float *const sdistL = lds + L.sdist;
-    float *const scenL = lds + L.scen;       // sphere centres + radius, only with self-collision
-    float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, only with self-collision
+    float *const scenL = lds + L.scen;       // centres + radius of the spheres that appear in pairs (detection), with self-collision
+    float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, [maxlev][NC3] (phase 4a); shares scen's storage
     int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
     int *const bchL = nsibL + n;                                    // base_children[n]
     int *const fchL = nsibL + 2 * n;                                // first_child[n]
@@ -290,7 +290,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
                 const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
                 sdistL[s] = ((meta & 0x100u) && (P.flags & F_GROUND)) ? c.z - sp.w : 1e30f;
-                if (P.flags & F_SELF) { st3(scenL + 4 * s, c); scenL[4 * s + 3] = sp.w; }
+                if ((P.flags & F_SELF) && (meta & 0x8000u)) {      // this sphere appears in a pair: keep its centre
+                    float *pc4 = scenL + 4 * (int)M->self_idx[s];
+                    st3(pc4, c); pc4[3] = sp.w;
+                }
             }
             wave_sync();
             int count = 0;
@@ -773,7 +776,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                             Y = f - sdot(ldsv(pc + 20), Z2);
                             Z2 = xforce_up(ldm(pc), ld3(pc + 9), sfma(ldsv(pc + 12), Y * pc[18], Z2));
                         }
-                        Yd2L[(dd - 1) * WAVE + lane] = Y;
+                        if (col >= 0) Yd2L[(dd - 1) * NC3 + col] = Y;
                     }
                 }
                 Z = Z + Z2;
@@ -816,7 +819,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const int d = (int)((inf >> 8) & 0xffu);
                 float Y = 0.f;
                 switch (d) { HG_Y_CASES default: break; }
-                if (two_body) { if ((myanc2 >> i) & 1ull) Y += Yd2L[(d - 1) * WAVE + lane]; }
+                if (two_body) { if ((myanc2 >> i) & 1ull) Y += Yd2L[(d - 1) * NC3 + col]; }      // myanc2 != 0 only on contact-row lanes
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
                 acur = a;

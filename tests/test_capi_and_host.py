@@ -150,6 +150,24 @@ def test_stats_allreduce_world2_gloo():
     assert "GLOO_STATS_OK" in out.stdout
 
 
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no RANK in the environment must start two ranks itself (BASELINE.json:
+    "at 1/2/4/8 MI355X") and print ONE line with n_gpus = 2.  --dry-sim swaps HgSim for a stand-in so that the
+    launcher, the env sharding and the statistics all-reduce run on CPU ranks over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-sim", "--steps", "3",
+                          "--warmup", "1", "--envs-per-gpu", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["backend"] == "gloo"
+    assert rec["global_env_steps"] == 2 * 64 * (3 + 1)              # both ranks' envs went through the all-reduce
+    assert rec["per_rank_ms_per_step"]["min"] <= rec["per_rank_ms_per_step"]["max"]
+    assert "DRY RUN" in rec["metric"] and rec["value"] == 0.0        # never mistaken for a measurement
+
+
 def test_box_space_fallback():
     b = spaces.Box(np.array([-1.0, 0.0], dtype=np.float32), np.array([1.0, 2.0], dtype=np.float32))
     for _ in range(10):
