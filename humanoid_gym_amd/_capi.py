@@ -135,7 +135,8 @@ class HgSim:
     def reset(self, env_mask=None):
         if env_mask is not None:
             env_mask = env_mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
-            assert env_mask.numel() == self.n_envs
+            if env_mask.numel() != self.n_envs:
+                raise HgError(f"env_mask must have {self.n_envs} entries (got {env_mask.numel()})")
         _check(self.L, self.L.hg_reset(self._h, _ptr(env_mask), self._stream()), "hg_reset")
 
     def step(self, actions=None, joint_sel: Optional[Sequence[int]] = None, n_substeps: int = 1):
@@ -196,7 +197,8 @@ class HgSim:
     def set_state(self, s):
         t = self.torch
         s = s.to(device=self.device, dtype=t.float32).contiguous()
-        assert tuple(s.shape) == (self.n_envs, self.state_size)
+        if tuple(s.shape) != (self.n_envs, self.state_size):
+            raise HgError(f"state must have shape ({self.n_envs}, {self.state_size}), got {tuple(s.shape)}")
         _check(self.L, self.L.hg_set_state(self._h, _ptr(s), self._stream()), "hg_set_state")
 
     def stats_accumulate(self, stats):
@@ -213,7 +215,8 @@ class HgSim:
             return
         t = self.torch
         cmd = cmd.to(device=self.device, dtype=t.float32).contiguous()
-        assert tuple(cmd.shape) == (self.n_envs, 3)
+        if tuple(cmd.shape) != (self.n_envs, 3):
+            raise HgError(f"base velocity command must have shape ({self.n_envs}, 3), got {tuple(cmd.shape)}")
         _check(self.L, self.L.hg_set_base_velocity(self._h, _ptr(cmd), self._stream()), "hg_set_base_velocity")
 
     def stats_flush(self, stats):

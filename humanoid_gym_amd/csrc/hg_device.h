@@ -2,8 +2,9 @@
 //
 // One wavefront (64 lanes) simulates one env.  The robot description is a
 // single read-only DevModel in HBM (about 30 KB, L2 resident); per-env state
-// is an env-major float record (include/hg_model.h, HG_STATE_SIZE) so that the
-// 64 lanes of the env's wave read and write it as one contiguous burst.
+// is an env-major float record (include/hg_model.h, HG_STATE_SIZE; padded in the library's own
+// buffer to a whole number of 64-byte lines) so that the 64 lanes of the env's wave read and write
+// it as one contiguous, line-aligned burst.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -66,6 +67,7 @@ enum { F_GROUND = 1, F_SELF = 2, F_CLAMP = 4, F_ACTIONS = 8, F_BASECMD = 16, F_L
 struct StepParams {
     int32_t n_envs, n_substeps, iters, maxc, n_sel, flags;
     int32_t flip_from;    // envs >= flip_from flip their wave priority at solver entry (F_PRIOFLIP)
+    int32_t state_stride; // floats between two envs' state records (HG_STATE_SIZE rounded up to a 64-byte line)
     // model sizes, repeated here so that they arrive with the kernel arguments (no dependent load from DevModel)
     int32_t n, n_spheres, n_pairs, n_act, maxlev, n_base_children, n_self;
     int8_t  lev_start[DMAX + 4];

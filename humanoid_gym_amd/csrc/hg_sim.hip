@@ -30,15 +30,29 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
                         std::string(#call) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
+// Makes `dev` current for the duration of one entry point and restores the caller's device afterwards:
+// torch reads its current device from the HIP runtime, so a library call must not change it behind its back.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define HG_DEVICE(s) DeviceGuard guard_((s)->device); HG_HIP(guard_.err)
+
 // ---------------------------------------------------------------------------------------
 // helper kernels
 // ---------------------------------------------------------------------------------------
 __global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__ state, float *__restrict__ torque,
-                             const uint8_t *__restrict__ mask, int n_envs) {
+                             const uint8_t *__restrict__ mask, int n_envs, int stride) {
     const int env = blockIdx.x;
     if (env >= n_envs || (mask && !mask[env])) return;
     const int n = M->n, S = HG_STATE_SIZE(n);
-    float *st = state + (size_t)env * S;
+    float *st = state + (size_t)env * stride;
     for (int k = threadIdx.x; k < n; k += blockDim.x) torque[(size_t)env * n + k] = 0.f;
     for (int k = threadIdx.x; k < S; k += blockDim.x) {
         float v = 0.f;
@@ -51,11 +65,11 @@ __global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__
 }
 
 __global__ void joint_state_kernel(const float *__restrict__ state, float *__restrict__ q,
-                                   float *__restrict__ qd, int n, int n_envs) {
+                                   float *__restrict__ qd, int n, int n_envs, int stride) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n_envs * n) return;
     const int env = (int)(i / n), j = (int)(i % n);
-    const float *st = state + (size_t)env * HG_STATE_SIZE(n);
+    const float *st = state + (size_t)env * stride;
     if (q) q[i] = st[HG_STATE_BASE + j];
     if (qd) qd[i] = st[HG_STATE_BASE + n + j];
 }
@@ -64,11 +78,11 @@ __global__ void joint_state_kernel(const float *__restrict__ state, float *__res
 __global__ __launch_bounds__(WAVE)
 void link_state_kernel(const DevModel *__restrict__ M, const float *__restrict__ state,
                        float *__restrict__ com_pos, float *__restrict__ com_quat,
-                       float *__restrict__ frame_pos, float *__restrict__ frame_quat) {
+                       float *__restrict__ frame_pos, float *__restrict__ frame_quat, int stride) {
     __shared__ float pub[(HG_MAX_LINKS + 1) * 12];
     const int env = blockIdx.x, lane = threadIdx.x;
     const int n = M->n;
-    const float *st = state + (size_t)env * HG_STATE_SIZE(n);
+    const float *st = state + (size_t)env * stride;
     const bool is_link = lane < n;
     const int li = is_link ? lane : 0;
     const float *lk = M->link[li];
@@ -107,6 +121,16 @@ void link_state_kernel(const DevModel *__restrict__ M, const float *__restrict__
         mat_to_quat(mul(Rw, quat_to_mat(fq[0], fq[1], fq[2], fq[3])), qq);
         for (int k = 0; k < 4; k++) frame_quat[4 * o + k] = qq[k];
     }
+}
+
+// state records between the caller's dense layout and the library's line-padded one: one thread per float
+__global__ void copy_records_kernel(float *__restrict__ dst, int dstride, const float *__restrict__ src, int sstride,
+                                    int width, int n_envs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_envs * width) return;
+    const size_t env = i / width;
+    const int k = (int)(i - env * width);
+    dst[env * dstride + k] = src[env * sstride + k];
 }
 
 __global__ void copy_contacts_kernel(const int32_t *__restrict__ pairs_in, const int32_t *__restrict__ counts_in,
@@ -165,6 +189,7 @@ __global__ void stats_flush_kernel(float *__restrict__ cum, float *__restrict__ 
 struct hg_sim {
     int device = 0;
     int n_envs = 0, n = 0, n_act = 0, state_size = 0;
+    int state_stride = 0;       // floats between two envs' records in d_state: state_size rounded up to a 64-byte line
     int variant = 0;            // index into the (NMX, MAXC) instantiation table
     int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0, n_self = 0;
     int8_t lev_start[hg::DMAX + 4]{};
@@ -405,7 +430,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     if (device_id < 0 || device_id >= ndev) { delete hm; return fail(HG_ENODEVICE, "hg_create: no such HIP device"); }
-    if (hipSetDevice(device_id) != hipSuccess) { delete hm; return fail(HG_ENODEVICE, "hg_create: hipSetDevice failed"); }
+    DeviceGuard guard_(device_id);
+    if (guard_.err != hipSuccess) { delete hm; return fail(HG_ENODEVICE, "hg_create: hipSetDevice failed"); }
 
     hg_sim *s = new (std::nothrow) hg_sim;
     if (!s) { delete hm; return fail(HG_ENOMEM, "hg_create: host allocation failed"); }
@@ -415,11 +441,13 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->n_self = hm->n_self;
     for (int l = 0; l < DMAX + 4; l++) s->lev_start[l] = (int8_t)hm->lev_start[l];
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
+    s->state_stride = (s->state_size + 15) & ~15;      // records start on 64-byte lines: no partial-line traffic
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
     s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
-    if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_size);
+    if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_stride);
+    if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(float) * (size_t)n_envs * s->state_stride);
     if (e == hipSuccess) e = hipMalloc(&s->d_link_mask, sizeof(unsigned long long) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
@@ -446,7 +474,7 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
 
 int hg_destroy(hg_sim *s) {
     if (!s) return HG_OK;
-    (void)hipSetDevice(s->device);
+    DeviceGuard guard_(s->device);
     (void)hipFree(s->d_model); (void)hipFree(s->d_state); (void)hipFree(s->d_link_mask);
     (void)hipFree(s->d_pairs); (void)hipFree(s->d_counts); (void)hipFree(s->d_cum); (void)hipFree(s->d_base_cmd);
     (void)hipFree(s->d_torque);
@@ -456,9 +484,9 @@ int hg_destroy(hg_sim *s) {
 
 int hg_reset(hg_sim *s, const uint8_t *env_mask_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_reset: null handle");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     hipLaunchKernelGGL(reset_kernel, dim3(s->n_envs), dim3(WAVE), 0, (hipStream_t)stream,
-                       s->d_model, s->d_state, s->d_torque, env_mask_dev, s->n_envs);
+                       s->d_model, s->d_state, s->d_torque, env_mask_dev, s->n_envs, s->state_stride);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }
@@ -481,7 +509,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     }
     const hg_config &c = s->cfg;
     P.n_envs = s->n_envs; P.n_substeps = n_substeps; P.iters = c.solver_iters; P.maxc = c.max_contacts;
-    P.n_sel = n_sel;
+    P.n_sel = n_sel; P.state_stride = s->state_stride;
     P.n = s->n; P.n_spheres = s->n_spheres; P.n_pairs = s->n_pairs; P.n_act = s->n_act; P.maxlev = s->maxlev;
     P.n_base_children = s->n_base_children; P.n_self = s->n_self;
     memcpy(P.lev_start, s->lev_start, sizeof P.lev_start);
@@ -509,7 +537,7 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     O.done = done_dev; O.collision = collision_dev;
     O.link_mask = s->d_link_mask; O.pairs = s->d_pairs; O.counts = s->d_counts; O.cum = s->d_cum; O.base_cmd = s->d_base_cmd;
     O.torque = s->d_torque;
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
     switch (s->variant) {
@@ -523,17 +551,17 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
 
 int hg_get_joint_states(hg_sim *s, float *q_dev, float *qd_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_get_joint_states: null handle");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     const size_t tot = (size_t)s->n_envs * s->n;
     hipLaunchKernelGGL(joint_state_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       s->d_state, q_dev, qd_dev, s->n, s->n_envs);
+                       s->d_state, q_dev, qd_dev, s->n, s->n_envs, s->state_stride);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }
 
 int hg_get_joint_torques(hg_sim *s, float *tau_dev, void *stream) {
     if (!s || !tau_dev) return fail(HG_EINVAL, "hg_get_joint_torques: null argument");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     HG_HIP(hipMemcpyAsync(tau_dev, s->d_torque, sizeof(float) * (size_t)s->n_envs * s->n, hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
     return HG_OK;
@@ -542,16 +570,16 @@ int hg_get_joint_torques(hg_sim *s, float *tau_dev, void *stream) {
 int hg_get_link_states(hg_sim *s, float *com_pos_dev, float *com_quat_dev, float *frame_pos_dev,
                        float *frame_quat_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_get_link_states: null handle");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     hipLaunchKernelGGL(link_state_kernel, dim3(s->n_envs), dim3(WAVE), 0, (hipStream_t)stream,
-                       s->d_model, s->d_state, com_pos_dev, com_quat_dev, frame_pos_dev, frame_quat_dev);
+                       s->d_model, s->d_state, com_pos_dev, com_quat_dev, frame_pos_dev, frame_quat_dev, s->state_stride);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }
 
 int hg_get_contact_pairs(hg_sim *s, int32_t *pairs_dev, int32_t *counts_dev, uint64_t *link_mask_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_get_contact_pairs: null handle");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     const size_t tot = (size_t)s->n_envs * HG_MAX_CONTACTS * 2;
     hipLaunchKernelGGL(copy_contacts_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        s->d_pairs, s->d_counts, s->d_link_mask, pairs_dev, counts_dev,
@@ -562,17 +590,22 @@ int hg_get_contact_pairs(hg_sim *s, int32_t *pairs_dev, int32_t *counts_dev, uin
 
 int hg_get_state(hg_sim *s, float *state_dev, void *stream) {
     if (!s || !state_dev) return fail(HG_EINVAL, "hg_get_state: null argument");
-    HG_HIP(hipSetDevice(s->device));
-    HG_HIP(hipMemcpyAsync(state_dev, s->d_state, sizeof(float) * (size_t)s->n_envs * s->state_size,
-                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HG_DEVICE(s);
+    // the caller's records are dense (HG_STATE_SIZE floats), the library's are padded to whole 64-byte lines
+    const size_t tot = (size_t)s->n_envs * s->state_size;
+    hipLaunchKernelGGL(copy_records_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       state_dev, s->state_size, s->d_state, s->state_stride, s->state_size, s->n_envs);
+    HG_HIP(hipGetLastError());
     return HG_OK;
 }
 
 int hg_set_state(hg_sim *s, const float *state_dev, void *stream) {
     if (!s || !state_dev) return fail(HG_EINVAL, "hg_set_state: null argument");
-    HG_HIP(hipSetDevice(s->device));
-    HG_HIP(hipMemcpyAsync(s->d_state, state_dev, sizeof(float) * (size_t)s->n_envs * s->state_size,
-                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HG_DEVICE(s);
+    const size_t tot = (size_t)s->n_envs * s->state_size;
+    hipLaunchKernelGGL(copy_records_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       s->d_state, s->state_stride, state_dev, s->state_size, s->state_size, s->n_envs);
+    HG_HIP(hipGetLastError());
     return HG_OK;
 }
 
@@ -590,7 +623,7 @@ int hg_get_layout(const hg_sim *s, int32_t *n_envs, int32_t *n_links, int32_t *n
 int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_dev, const uint8_t *collision_dev,
                         float *stats_dev, void *stream) {
     if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_accumulate: null argument");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     int blocks = (s->n_envs + 255) / 256;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -601,7 +634,7 @@ int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_
 
 int hg_set_base_velocity(hg_sim *s, const float *cmd_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_set_base_velocity: null handle");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     if (!cmd_dev) { s->base_cmd_on = false; return HG_OK; }
     if (!s->d_base_cmd) {
         if (hipMalloc(&s->d_base_cmd, sizeof(float) * 3 * (size_t)s->n_envs) != hipSuccess) {
@@ -617,7 +650,7 @@ int hg_set_base_velocity(hg_sim *s, const float *cmd_dev, void *stream) {
 
 int hg_stats_flush(hg_sim *s, float *stats_dev, void *stream) {
     if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_flush: null argument");
-    HG_HIP(hipSetDevice(s->device));
+    HG_DEVICE(s);
     int blocks = (s->n_envs + 255) / 256;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(stats_flush_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_cum, stats_dev, s->n_envs);

@@ -141,7 +141,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     HG_TICK_HWID();
     const bool is_link = lane < n;
     const int S = HG_STATE_SIZE(n);
-    float *const st = state + (size_t)env * S;
+    float *const st = state + (size_t)env * P.state_stride;
 
     // ---- per-lane link constants --------------------------------------------------
     const int li = is_link ? lane : 0;

@@ -437,6 +437,17 @@ def load_urdf(path: str,
                 s_pos.append(body_RL[b + 1].T @ (p_car - body_com[b + 1]))
                 s_rad.append(r)
 
+    # A body's spheres must be contiguous (the "4 deepest points per body" rule ranks inside one run, and
+    # hg_create verifies it).  link_body is in link-DFS order, so a carrier link whose welded (fixed-joint)
+    # child is declared after a revolute sibling subtree would otherwise emit two separate runs: group by
+    # body with a stable sort, which leaves the order inside each body as declared.
+    if s_link:
+        order = sorted(range(len(s_link)), key=lambda k: s_link[k])
+        s_link = [s_link[k] for k in order]
+        s_flag = [s_flag[k] for k in order]
+        s_pos = [s_pos[k] for k in order]
+        s_rad = [s_rad[k] for k in order]
+
     # self-collision pairs: different bodies, neither an ancestor of the other
     # (URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, dancer_env.py:60)
     pair_a, pair_b = [], []

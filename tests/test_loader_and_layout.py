@@ -190,3 +190,48 @@ def test_dancer_ground_points_come_from_the_reference_meshes():
         for s in idx:
             p_link = R.T @ (m.sphere_pos[s] - m.frame_pos[b + 1])
             assert np.abs(verts - p_link).sum(1).min() < 1e-6, (m.link_names_all[b], s)
+
+
+def test_welded_child_after_revolute_sibling_keeps_a_bodys_spheres_contiguous(tmp_path):
+    """A carrier link with collision geometry, a revolute child subtree, and THEN a fixed-joint child that
+    carries more collision geometry (real SoftBank URDFs are full of welded links): the carrier's spheres
+    come from two links visited at different times, and must still form one run per body -- hg_create
+    rejects a model otherwise ('collision spheres of one body must be contiguous')."""
+    import ctypes as C
+    from humanoid_gym_amd import _capi
+    from humanoid_gym_amd.model import SimConfig
+    from humanoid_gym_amd.urdf import load_urdf
+
+    def link(name, box=None):
+        col = f'<collision><geometry><box size="{box} {box} {box}"/></geometry></collision>' if box else ""
+        return (f'<link name="{name}"><inertial><mass value="0.2"/><inertia ixx="1e-3" ixy="0" ixz="0" iyy="1e-3" '
+                f'iyz="0" izz="1e-3"/></inertial>{col}</link>')
+
+    def joint(name, kind, parent, child, xyz):
+        lim = '<limit lower="-1" upper="1" effort="5" velocity="5"/>' if kind == "revolute" else ""
+        return (f'<joint name="{name}" type="{kind}"><parent link="{parent}"/><child link="{child}"/>'
+                f'<origin xyz="{xyz}"/><axis xyz="0 1 0"/>{lim}</joint>')
+
+    text = "<robot name=\"welded\">" + "".join([
+        link("base", 0.1), link("arm", 0.04), link("hand", 0.03), link("lid", 0.05), link("tip", 0.02),
+        joint("j_arm", "revolute", "base", "arm", "0 0.1 0"),
+        joint("j_hand", "revolute", "arm", "hand", "0 0.1 0"),
+        joint("w_lid", "fixed", "base", "lid", "0 0 0.1"),            # welded to the base, declared after the arm subtree
+        joint("w_tip", "fixed", "arm", "tip", "0 0.05 0.05"),         # welded to the arm, declared after its revolute child
+    ]) + "</robot>"
+    path = tmp_path / "welded.urdf"
+    path.write_text(text)
+    m = load_urdf(str(path), self_collision=True, name="welded")
+    assert m.n_links == 2 and m.joint_names_all == ["j_arm", "j_hand", "w_tip", "w_lid"]      # DFS, declaration order
+    sl = m.sphere_link.tolist()
+    runs = [b for k, b in enumerate(sl) if k == 0 or sl[k - 1] != b]
+    assert len(runs) == len(set(runs)) and set(sl) == {-1, 0, 1}, sl                         # one run per body
+    assert sl.count(-1) > 8 and sl.count(0) > 8                                               # base+lid, arm+tip merged
+    assert all(m.sphere_link[a] != m.sphere_link[b] for a, b in zip(m.pair_a, m.pair_b))
+    L = _capi.load_library()
+    h = C.c_void_p()
+    cm, cc = m.to_c(), SimConfig(enable_self=True).to_c()
+    rc = L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h))
+    assert rc in (0, -2), (rc, L.hg_last_error())           # accepted: 0 on a GPU box, "no device" here -- never HG_EINVAL
+    if rc == 0:
+        L.hg_destroy(h)
