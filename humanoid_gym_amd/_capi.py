@@ -21,7 +21,7 @@ _lib = None
 SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_reset", "hg_step",
            "hg_get_joint_states", "hg_get_link_states", "hg_get_contact_pairs", "hg_get_state",
            "hg_set_state", "hg_get_layout", "hg_stats_accumulate", "hg_stats_flush",
-           "hg_set_base_velocity", "hg_get_joint_torques"]
+           "hg_set_base_velocity", "hg_get_joint_torques", "hg_stats_accumulate_noalloc"]
 
 
 class HgError(RuntimeError):
@@ -67,6 +67,8 @@ def load_library(path: Optional[str] = None):
     L.hg_get_layout.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     L.hg_stats_accumulate.restype = C.c_int
     L.hg_stats_accumulate.argtypes = [C.c_void_p, fp, u8p, u8p, fp, vp]
+    L.hg_stats_accumulate_noalloc.restype = C.c_int
+    L.hg_stats_accumulate_noalloc.argtypes = [C.c_void_p, fp, u8p, u8p, fp, vp]
     L.hg_set_base_velocity.restype = C.c_int
     L.hg_set_base_velocity.argtypes = [C.c_void_p, fp, vp]
     L.hg_stats_flush.restype = C.c_int

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -179,6 +180,58 @@ __global__ void stats_flush_kernel(float *__restrict__ cum, float *__restrict__ 
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(stats + 0, a.x); atomicAdd(stats + 1, a.y); atomicAdd(stats + 2, a.z); atomicAdd(stats + 3, a.w);
     }
+}
+
+// ---- hg_stats_accumulate_noalloc: fixed-order two-stage reduction through a static device array --------------
+// Stage 1 writes one partial {envs, reward, done, collision} per 1024 envs into `scratch`, stage 2 (one workgroup)
+// adds them up in slot order and adds the totals to the caller's vector.  No atomics: the sum does not depend on
+// which workgroup finishes first.  The array is a file-scope device symbol, so no call ever allocates; every GPU
+// the library runs on holds its own copy (16 KB) until the process ends.
+constexpr int NOALLOC_ENVS_PER_SLOT = 1024;                        // 256 threads x 4 envs
+constexpr int NOALLOC_SLOTS = HG_NOALLOC_MAX_ENVS / NOALLOC_ENVS_PER_SLOT;
+static __device__ __align__(256) float scratch[NOALLOC_SLOTS * 4];
+
+__device__ inline float4 block_sum4(float4 a, float4 *sh) {        // 256 threads = 4 waves, fixed order
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a.x += __shfl_xor(a.x, o); a.y += __shfl_xor(a.y, o); a.z += __shfl_xor(a.z, o); a.w += __shfl_xor(a.w, o);
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    float4 r = sh[0];
+    for (int w = 1; w < 4; w++) { r.x += sh[w].x; r.y += sh[w].y; r.z += sh[w].z; r.w += sh[w].w; }
+    return r;
+}
+
+__global__ __launch_bounds__(256)
+void stats_partial_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
+                          const uint8_t *__restrict__ collision, float *__restrict__ part, int n_envs) {
+    __shared__ float4 sh[4];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int base = blockIdx.x * NOALLOC_ENVS_PER_SLOT;
+    for (int k = 0; k < 4; k++) {
+        const int i = base + k * 256 + threadIdx.x;
+        if (i < n_envs) {
+            a.x += 1.f;
+            if (reward) a.y += reward[i];
+            if (done) a.z += done[i] ? 1.f : 0.f;
+            if (collision) a.w += collision[i] ? 1.f : 0.f;
+        }
+    }
+    const float4 r = block_sum4(a, sh);
+    if (threadIdx.x == 0) reinterpret_cast<float4 *>(part)[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256)
+void stats_final_kernel(const float *__restrict__ part, int n_slots, float *__restrict__ stats) {
+    __shared__ float4 sh[4];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = threadIdx.x; k < n_slots; k += 256) {             // only the slots stage 1 of THIS call wrote
+        const float4 p = reinterpret_cast<const float4 *>(part)[k];
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    const float4 r = block_sum4(a, sh);
+    if (threadIdx.x == 0) { stats[0] += r.x; stats[1] += r.y; stats[2] += r.z; stats[3] += r.w; }
 }
 
 }  // namespace hg
@@ -628,6 +681,41 @@ int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        reward_dev, done_dev, collision_dev, stats_dev, s->n_envs);
+    HG_HIP(hipGetLastError());
+    return HG_OK;
+}
+
+// Device address of `scratch` on each GPU, resolved once per device with that device current: in host code the
+// symbol's name is only a handle for hipGetSymbolAddress, never a pointer a kernel could use.
+static float *g_scratch_ptr[HG_NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+int hg_stats_accumulate_noalloc(hg_sim *s, const float *reward_dev, const uint8_t *done_dev, const uint8_t *collision_dev,
+                                float *stats_dev, void *stream) {
+    if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_accumulate_noalloc: null argument");
+    if (s->n_envs > HG_NOALLOC_MAX_ENVS)
+        return fail(HG_EUNSUPPORTED, "hg_stats_accumulate_noalloc: n_envs = " + std::to_string(s->n_envs) + " exceeds HG_NOALLOC_MAX_ENVS = " +
+                                     std::to_string(HG_NOALLOC_MAX_ENVS) + " (the static scratch array holds one partial per 1024 envs)");
+    if (s->device < 0 || s->device >= HG_NOALLOC_MAX_DEVICES)
+        return fail(HG_EUNSUPPORTED, "hg_stats_accumulate_noalloc: device index beyond HG_NOALLOC_MAX_DEVICES");
+    HG_DEVICE(s);
+    float *part = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[s->device]) {
+            void *p = nullptr;
+            HG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(hg::scratch)));      // this device's copy (s->device is current)
+            g_scratch_ptr[s->device] = static_cast<float *>(p);
+        }
+        part = g_scratch_ptr[s->device];
+    }
+    // Nothing in the array has to start at zero: stage 2 reads exactly the n_slots partials that stage 1 of this
+    // call has just written on the same stream; slots beyond them keep an earlier call's contents and are not read.
+    const int n_slots = (s->n_envs + NOALLOC_ENVS_PER_SLOT - 1) / NOALLOC_ENVS_PER_SLOT;
+    hipLaunchKernelGGL(stats_partial_kernel, dim3(n_slots), dim3(256), 0, (hipStream_t)stream,
+                       reward_dev, done_dev, collision_dev, part, s->n_envs);
+    HG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n_slots, stats_dev);
     HG_HIP(hipGetLastError());
     return HG_OK;
 }

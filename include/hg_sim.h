@@ -146,6 +146,20 @@ int hg_stats_accumulate(hg_sim *sim, const float *reward_dev, const uint8_t *don
                         const uint8_t *collision_dev, float *stats_dev, void *stream);
 
 /*
+ * hg_stats_accumulate for callers that must not allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and result as hg_stats_accumulate, computed as a fixed-order two-stage sum (no atomics: bit-reproducible
+ * from run to run) whose partial results live in a static device array of the library, 16 KB per GPU for
+ * the life of the process.  It calls no hipMalloc / hipFree.  Limits: n_envs of the sim <= HG_NOALLOC_MAX_ENVS
+ * (HG_EUNSUPPORTED beyond), device index < HG_NOALLOC_MAX_DEVICES.  All calls on one GPU share that GPU's
+ * array: calls that may overlap on one GPU (different streams, different sims) race; order them.
+ */
+#define HG_NOALLOC_MAX_ENVS    (1 << 20)
+#define HG_NOALLOC_MAX_DEVICES 64
+int hg_stats_accumulate_noalloc(hg_sim *sim, const float *reward_dev, const uint8_t *done_dev,
+                                const uint8_t *collision_dev, float *stats_dev, void *stream);
+
+/*
  * Commanded planar base velocity, the three leading action slots that
  * PepperEnv declares and never consumes (pepper_env.py:53 vs :61; qibullet
  * exposes the same motion as PepperVirtual.move(x, y, theta)).
