@@ -96,7 +96,7 @@ struct LdsPlan {
 // two-body rows, kept for the contact-row lanes only (maxlev x nc3, phase 4a).
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
@@ -104,7 +104,7 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.jw = o;    o += 8 * n;
     p.base = o;  o += 64;
     p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
-    p.lam = o;   p.misc = o; o += 64;
+    p.lam = o;   p.misc = o; o += nrows > WAVE ? WAVE + rup4(nc3) : WAVE;      // impulses of all rows (two rows per lane beyond 64)
     p.con = o;   o += CON * (nc3 / 3);
     p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
     p.sdist = o; o += rup4(ns);

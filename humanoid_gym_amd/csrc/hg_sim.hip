@@ -273,7 +273,9 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
     X(5, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
     X(6, 37, 8, 12, 2, 3)  /* romeo: 61 rows, 3 lanes left for limits  */ \
     X(7, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
-    X(8, 46, 6, 12, 2, 3)  /* anything up to 46 dofs                   */
+    X(8, 46, 6, 12, 2, 3)  /* anything up to 46 dofs, 6 contacts       */ \
+    X(9, 44, 8, 12, 2, 2)  /* nao with finger joints (42 dofs): 68 rows, two rows per lane */ \
+    X(10, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows            */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -440,7 +442,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 4; }
+int hg_abi_version(void) { return 5; }
 
 #ifdef HG_PHASE_TIMING
 // diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch
@@ -496,7 +498,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     s->state_stride = (s->state_size + 15) & ~15;      // records start on 64-byte lines: no partial-line traffic
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
-    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self).total;
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self,
+                                                       kVariants[variant].nmx + 3 * kVariants[variant].maxc).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_stride);

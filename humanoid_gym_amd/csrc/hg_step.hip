@@ -89,6 +89,22 @@ HG_FI void wave_sync() {
 template <int N> struct RegVec { typedef float type __attribute__((ext_vector_type(N))); };
 constexpr int clamp16(int x) { return x < 1 ? 1 : (x > 16 ? 16 : x); }
 
+// What a lane knows about one constraint row it owns (set up in phase 4, consumed by the impulse response).
+struct RowVars {
+    int body, body2, col;                 // link the row acts on (-1 base), second body of a self-contact row (< -1: none), contact column
+    float target_err, unit_f;             // desired change of J.v; the one Jacobian entry of a motor / limit row
+    V3 Jang, Jlin;                        // base columns of a contact row
+    unsigned long long myanc, myanc2;     // ancestor masks of body / body2
+    unsigned pw[3], pw2[3];               // packed paths (ancestor-or-self per depth) of body / body2
+    bool contact, motor, slot, two_body;
+    HG_FI void clear() {
+        body = -1; body2 = -3; col = -1; target_err = 0.f; unit_f = 0.f;
+        Jang = v3(0, 0, 0); Jlin = v3(0, 0, 0); myanc = 0ull; myanc2 = 0ull;
+        pw[0] = pw[1] = pw[2] = 0u; pw2[0] = pw2[1] = pw2[2] = 0u;
+        contact = motor = slot = two_body = false;
+    }
+};
+
 // NMX: motor-row lanes (>= n dofs), MAXC: contact slots, DEPTH: deepest link level handled,
 // NSL: saved-acceleration slots for branching links, WPE: waves per SIMD the register budget targets.
 template <int NMX, int MAXC, int DEPTH, int NSL, int WPE>
@@ -98,7 +114,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 {
     constexpr int NC3 = 3 * MAXC;
     constexpr int NROWS = NMX + NC3;
-    static_assert(NROWS <= WAVE, "rows must fit one wavefront");
+    static_assert(NMX <= WAVE && NC3 <= WAVE, "motor rows and contact rows each fit one wavefront (two rows per lane beyond 64 rows)");
     static_assert((6 * NC3) % 4 == 0, "the joint part of Jc must start on a 16-byte boundary (even MAXC)");
 
     extern __shared__ __align__(16) float lds[];
@@ -109,7 +125,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = P.n_spheres;
     const int maxlev = P.maxlev;
-    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self);
+    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self, NROWS);
     // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
     // leave them in VGPRs that stay live for the whole kernel)
     L.AB = __builtin_amdgcn_readfirstlane(L.AB);
@@ -171,6 +187,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const float w0 = st[lane < S ? lane : 0], w1 = st[WAVE + lane < S ? WAVE + lane : 0];
         const float w2 = lk[L_R0], w3 = lk[L_D + 1], w4 = lk[LINKC - 1];       // one word per 64-byte line of the link record
         warm = w0 + w1 + w2 + w3 + w4;
+        if constexpr (NMX > 38) warm += st[2 * WAVE + lane < S ? 2 * WAVE + lane : 0];      // records beyond 128 floats
+        if constexpr (NMX > 59) warm += st[3 * WAVE + lane < S ? 3 * WAVE + lane : 0];
     }
     if (P.flags & F_ACTIONS) {
         float tgt = is_link ? st[HG_STATE_BASE + 2 * n + lane] : 0.f;
@@ -551,45 +569,53 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (is_link) { velL[6 + lane] = qd; accL[lane] = qd; }     // accL: parked until the end of the substep (accelerations are dead)
         wave_sync();      // region AB (pub/up) is dead from here on: Jc may overwrite it
 
-        const int col = (lane >= NMX && lane < NROWS) ? lane - NMX : -1;   // contact-row column
-        const int cidx = col < 0 ? -1 : (col < MAXC ? col : (col - MAXC) >> 1);
-        const bool row_contact = cidx >= 0 && cidx < nc;
-        const bool row_motor = is_link;                  // NMX >= n by construction
-        int body = row_motor ? lane : -1;
-        int body2 = -3;                                  // second body of a self-contact row, else < -1
-        float target_err = 0.f;                          // desired change of J.v
-        V3 Jang = v3(0, 0, 0), Jlin = v3(0, 0, 0);
-        // ancestor mask and packed path (ancestor-or-self per depth) of the bodies a contact row acts on
-        unsigned long long myanc = 0ull, myanc2 = 0ull;
-        unsigned pw[3] = {0u, 0u, 0u}, pw2[3] = {0u, 0u, 0u};
+        // ---- row layout ---------------------------------------------------------------------------------
+        // Up to 64 rows (every robot without finger joints): ONE row per lane -- motor rows on lanes < NMX, contact
+        // rows on lanes NMX .. NROWS-1, up to four violated joint limits on the spare lanes.
+        // More rows than lanes (DUAL: the 42-dof NAO with its fingers and 8 contacts has 66 rows, a Romeo with hands
+        // 85): every lane carries TWO rows, row set 0 = the motor row of joint `lane`, row set 1 = contact row `lane`
+        // (lanes < NC3).  Both sets run the same row set-up and impulse-response code below; the solver keeps both
+        // candidates per lane and every row update touches both.
+        constexpr bool DUAL = NROWS > WAVE;
+        constexpr int CB = DUAL ? 0 : NMX;         // lane of contact column 0 (in row set 1 when DUAL)
+        constexpr int CBL = DUAL ? WAVE : NMX;     // index of contact impulse 0 in lamL
+        RowVars R0, R1;                             // R1 is dead code unless DUAL
+        R0.clear(); R1.clear();
+        RowVars &RC = *(DUAL ? &R1 : &R0);          // the set that carries the contact rows
+        RC.col = (lane >= CB && lane < CB + NC3) ? lane - CB : -1;          // contact-row column
+        const int cidx = RC.col < 0 ? -1 : (RC.col < MAXC ? RC.col : (RC.col - MAXC) >> 1);
+        RC.contact = cidx >= 0 && cidx < nc;
+        R0.motor = is_link;                              // NMX >= n by construction
+        if (R0.motor) R0.body = lane;
         unsigned long long rowmask = 0ull;       // links with a non-zero row in Jc (wave-uniform)
         if (nc > 0) {
+            const int col = RC.col;
             V3 pt = v3(0, 0, 0), dir = v3(0, 0, 0);
             float dist = 0.f;
-            if (row_contact) {
+            if (RC.contact) {
                 const float *co = conL + CON * cidx;
-                body = __float_as_int(co[0]);
-                body2 = __float_as_int(co[1]);
+                RC.body = __float_as_int(co[0]);
+                RC.body2 = __float_as_int(co[1]);
                 pt = ld3(co + 2);
                 const V3 nrm = ld3(co + 5);
                 dist = co[8];
                 V3 t1, t2;
                 plane_space(nrm, t1, t2);
                 dir = col < MAXC ? nrm : (((col - MAXC) & 1) ? t2 : t1);
-                if (body >= 0) {
-                    myanc = M->anc_mask[body];
-                    const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
-                    pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
+                if (RC.body >= 0) {
+                    RC.myanc = M->anc_mask[RC.body];
+                    const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[RC.body]);
+                    RC.pw[0] = t.x; RC.pw[1] = t.y; RC.pw[2] = t.z;
                 }
-                if (body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
-                    if (body2 >= 0) {
-                        myanc2 = M->anc_mask[body2];
-                        const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body2]);
-                        pw2[0] = t.x; pw2[1] = t.y; pw2[2] = t.z;
+                if (RC.body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
+                    if (RC.body2 >= 0) {
+                        RC.myanc2 = M->anc_mask[RC.body2];
+                        const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[RC.body2]);
+                        RC.pw2[0] = t.x; RC.pw2[1] = t.y; RC.pw2[2] = t.z;
                     }
                 } else {
-                    Jang = cross(pt - ld3(baseL + 9), dir);
-                    Jlin = dir;
+                    RC.Jang = cross(pt - ld3(baseL + 9), dir);
+                    RC.Jlin = dir;
                 }
             }
             // joint part of Jc: zero everywhere ...
@@ -605,12 +631,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             wave_sync();
             // ... except on the path(s) from the contact bodies to the base: at most DEPTH entries per column
             float rv = 0.f;
-            const bool two = __ballot(myanc2 != 0ull) != 0ull;
-            if (row_contact) {
+            const bool two = __ballot(RC.myanc2 != 0ull) != 0ull;
+            if (RC.contact) {
 #pragma unroll
                 for (int dd = 1; dd <= DEPTH; ++dd) {
                     if (dd <= maxlev) {      // wave-uniform
-                        const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        const int l = (int)((RC.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                         if (l >= 0) {
                             const float *pj = jwL + 8 * l;
                             const float j = dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
@@ -624,7 +650,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                     for (int dd = 1; dd <= DEPTH; ++dd) {
                         if (dd <= maxlev) {
-                            const int l = (int)((pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                            const int l = (int)((RC.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                             if (l >= 0) {
                                 const float *pj = jwL + 8 * l;
                                 const float j = -dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
@@ -636,46 +662,46 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
             }
             if (col >= 0) {
-                JcL[0 * NC3 + col] = Jang.x; JcL[1 * NC3 + col] = Jang.y; JcL[2 * NC3 + col] = Jang.z;
-                JcL[3 * NC3 + col] = Jlin.x; JcL[4 * NC3 + col] = Jlin.y; JcL[5 * NC3 + col] = Jlin.z;
-                rv += dot(Jang, ld3(velL)) + dot(Jlin, ld3(velL + 3));
+                JcL[0 * NC3 + col] = RC.Jang.x; JcL[1 * NC3 + col] = RC.Jang.y; JcL[2 * NC3 + col] = RC.Jang.z;
+                JcL[3 * NC3 + col] = RC.Jlin.x; JcL[4 * NC3 + col] = RC.Jlin.y; JcL[5 * NC3 + col] = RC.Jlin.z;
+                rv += dot(RC.Jang, ld3(velL)) + dot(RC.Jlin, ld3(velL + 3));
             }
-            if (row_contact) {
+            if (RC.contact) {
                 if (col < MAXC) {
-                    target_err = -rv;
-                    if (dist > 0.f) target_err -= dist * P.inv_dt;
-                    else target_err -= dist * P.erp * P.inv_dt;
+                    RC.target_err = -rv;
+                    if (dist > 0.f) RC.target_err -= dist * P.inv_dt;
+                    else RC.target_err -= dist * P.erp * P.inv_dt;
                 } else {
-                    target_err = -rv;
+                    RC.target_err = -rv;
                 }
             }
             // which links have a non-zero row in Jc: OR of the ancestor masks of the contact bodies, read
-            // from the normal rows (lane NMX + c) on the scalar unit
+            // from the normal rows (lane CB + c) on the scalar unit
             {
-                const unsigned long long m = myanc | myanc2;
+                const unsigned long long m = RC.myanc | RC.myanc2;
                 const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
                 unsigned rlo = 0u, rhi = 0u;
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
                     if (c < nc) {
-                        rlo |= (unsigned)__builtin_amdgcn_readlane(mlo, NMX + c);
-                        if constexpr (NMX > 32) rhi |= (unsigned)__builtin_amdgcn_readlane(mhi, NMX + c);
+                        rlo |= (unsigned)__builtin_amdgcn_readlane(mlo, CB + c);
+                        if constexpr (NMX > 32) rhi |= (unsigned)__builtin_amdgcn_readlane(mhi, CB + c);
                     }
                 rowmask = ((unsigned long long)rhi << 32) | rlo;
             }
         }
-        if (row_motor) {
+        if (R0.motor) {
             const float tgt = st[HG_STATE_BASE + 2 * n + lane];
             float tv = fmaf(P.kp * (tgt - q), P.inv_dt, qd) - P.kd * qd;
             const float maxvel = cacheL[CACHE * lane + 26];
             tv = fminf(fmaxf(tv, -maxvel), maxvel);
-            target_err = tv - qd;
+            R0.target_err = tv - qd;
         }
         // Joint-limit rows (btMultiBodyJointLimitConstraint): one per violated bound, Jacobian +-1 on the joint
         // (so its impulse response is +- the motor row's: the row shares the motor's lane), desired
         // velocity 0 with the Baumgarte term -penetration * erp / dt, impulse in [0, limhi].
         float lim_s = 0.f, lim_b = 0.f;
-        if (row_motor && (P.flags & F_LIMITS)) {
+        if (R0.motor && (P.flags & F_LIMITS)) {
             const float *lkl = M->link[lane];
             if (lkl[L_LIMITED] != 0.f) {
                 const float pen_lo = q - lkl[L_LOWER], pen_hi = lkl[L_UPPER] - q;
@@ -686,20 +712,18 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         const unsigned long long limmask = __ballot(lim_s != 0.f);       // wave-uniform
-        // Limit rows on spare lanes.  The wave has 64 - NROWS lanes without a row; up to KL of them take one
-        // violated joint limit each and become ordinary rows: lane NROWS + k (slot k) carries a row with
+        // Limit rows on spare lanes (one row per lane only).  The wave has 64 - NROWS lanes without a row; up to KL of
+        // them take one violated joint limit each and become ordinary rows: lane NROWS + k (slot k) carries a row with
         // Jacobian slot_f = +-1 on joint slot_joint[k], so the impulse-response pass below computes its
         // A-row like any other lane's at no extra instruction.  Envs with more violated joints than
-        // slots (and the variants with no spare lane) take the generic path in the solver.
-        constexpr int KL = (WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4;
+        // slots (and the variants with no spare lane, and the two-rows-per-lane variants) take the generic path in the solver.
+        constexpr int KL = DUAL ? 0 : ((WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4);
         const int nlim = __popcll(limmask);
         const bool use_slots = KL > 0 && nlim > 0 && nlim <= KL;      // wave-uniform
         int slot_joint[KL > 0 ? KL : 1];
         float slot_sign[KL > 0 ? KL : 1];
 #pragma unroll
         for (int k = 0; k < (KL > 0 ? KL : 1); k++) { slot_joint[k] = 0; slot_sign[k] = 0.f; }
-        bool row_slot = false;
-        float slot_f = 0.f;
         if constexpr (KL > 0) {
             if (use_slots) {
                 unsigned long long mk = limmask;
@@ -711,35 +735,45 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         const float sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s), i));
                         const float b0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_b), i));
                         slot_joint[k] = i; slot_sign[k] = sg;
-                        if (lane == NROWS + k) { row_slot = true; slot_f = sg; body = i; target_err = b0; }
+                        if (lane == NROWS + k) { R0.slot = true; R0.unit_f = sg; R0.body = i; R0.target_err = b0; }
                     }
                 }
             }
         }
-        const bool row_active = row_motor || row_contact || row_slot;
-        if (row_motor || row_slot) {     // motor and limit rows act on one link
-            myanc = M->anc_mask[body];
-            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[body]);
-            pw[0] = t.x; pw[1] = t.y; pw[2] = t.z;
+        if (R0.motor) R0.unit_f = 1.f;           // the one non-zero Jacobian entry of a motor / limit row
+        if (R0.motor || R0.slot) {     // motor and limit rows act on one link
+            R0.myanc = M->anc_mask[R0.body];
+            const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[R0.body]);
+            R0.pw[0] = t.x; R0.pw[1] = t.y; R0.pw[2] = t.z;
         }
-        const float unit_f = row_motor ? 1.f : slot_f;     // the one non-zero Jacobian entry of such a row
-        const bool two_body = __ballot(myanc2 != 0ull) != 0ull;   // wave-uniform
+        RC.two_body = __ballot(RC.myanc2 != 0ull) != 0ull;   // wave-uniform
         wave_sync();
 
         HG_TICK(7);
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
         // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
         // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
-        // instead of a 48-way switch; contact columns: plain registers, compile-time indices only.
+        // instead of a 64-way switch; contact columns: plain registers, compile-time indices only.
         typedef typename RegVec<clamp16(NMX)>::type VA0;
         typedef typename RegVec<clamp16(NMX - 16)>::type VA1;
         typedef typename RegVec<clamp16(NMX - 32)>::type VA2;
-        VA0 AM0 = (VA0)(0.f); VA1 AM1 = (VA1)(0.f); VA2 AM2 = (VA2)(0.f);      // columns 0-15, 16-31, 32-47
+        typedef typename RegVec<clamp16(NMX - 48)>::type VA3;
+        VA0 AM0 = (VA0)(0.f); VA1 AM1 = (VA1)(0.f); VA2 AM2 = (VA2)(0.f); VA3 AM3 = (VA3)(0.f);     // columns 0-15, 16-31, 32-47, 48-63
         float AC[NC3 > 0 ? NC3 : 1];
 #pragma unroll
         for (int k = 0; k < NC3; k++) AC[k] = 0.f;
         float diag = 0.f;
-        {
+        // the same for the contact rows of row set 1 (DUAL only; dead code otherwise)
+        VA0 BM0 = (VA0)(0.f); VA1 BM1 = (VA1)(0.f); VA2 BM2 = (VA2)(0.f); VA3 BM3 = (VA3)(0.f);
+        float BC[NC3 > 0 ? NC3 : 1];
+#pragma unroll
+        for (int k = 0; k < NC3; k++) BC[k] = 0.f;
+        float diagB = 0.f;
+        auto response = [&](const RowVars &R, VA0 &XM0, VA1 &XM1, VA2 &XM2, VA3 &XM3, float (&XC)[NC3 > 0 ? NC3 : 1], float &xdiag)
+                            __attribute__((always_inline)) {
+            const int col = R.col, body = R.body;
+            const bool unit_row = R.motor || R.slot;
+            const unsigned pw[3] = {R.pw[0], R.pw[1], R.pw[2]};
             // (i) walk the own path towards the root, accumulating the zero-acceleration force
             Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
             float Ys[DEPTH];             // Y of the own-path link at each depth (registers)
@@ -750,7 +784,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                     if (l >= 0) {
                         const float *pc = cacheL + CACHE * l;
-                        const float f = (row_motor || row_slot) ? (l == body ? unit_f : 0.f) : JcL[(6 + l) * NC3 + col];
+                        const float f = unit_row ? (l == body ? R.unit_f : 0.f) : JcL[(6 + l) * NC3 + col];
                         const Sv Sl = ldsv(pc + 20);
                         const Sv Ul = ldsv(pc + 12);
                         Y = f - sdot(Sl, Z);
@@ -759,7 +793,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 Ys[dd - 1] = Y;
             }
-            if (two_body) {
+            if (R.two_body) {
                 // The impulse of a self-contact row acts on two branches.  By linearity the second
                 // branch is walked on its own (its force entries are already in Jc with their sign);
                 // the zero-acceleration forces meet at the base.
@@ -768,11 +802,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 for (int dd = DEPTH; dd >= 1; --dd) {
                     float Y = 0.f;
                     if (dd <= maxlev) {
-                        const int l = (int)((pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        const int l = (int)((R.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                         if (l >= 0) {
                             const float *pc = cacheL + CACHE * l;
                             // entries of links shared with the first branch are zero in Jc (they cancel)
-                            const float f = ((myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];
+                            const float f = ((R.myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];
                             Y = f - sdot(ldsv(pc + 20), Z2);
                             Z2 = xforce_up(ldm(pc), ld3(pc + 9), sfma(ldsv(pc + 12), Y * pc[18], Z2));
                         }
@@ -783,17 +817,17 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
             // (ii) base
             const M3 Rb = ldm(baseL);
-            Z.a = Z.a - tmulv(Rb, Jang);
-            Z.l = Z.l - tmulv(Rb, Jlin);
+            Z.a = Z.a - tmulv(Rb, R.Jang);
+            Z.l = Z.l - tmulv(Rb, R.Jlin);
             const Sv ab = neg_mul6(baseL + 12, Z);       // IA0^-1 streamed from LDS
             const V3 uba = mulv(Rb, ab.a), ubl = mulv(Rb, ab.l);
-            diag = dot(uba, Jang) + dot(ubl, Jlin);
+            xdiag = dot(uba, R.Jang) + dot(ubl, R.Jlin);
             if (nc > 0) {
                 const float ub[6] = {uba.x, uba.y, uba.z, ubl.x, ubl.y, ubl.z};
 #pragma unroll
                 for (int k = 0; k < 6; k++)
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) AC[c] = fmaf(ub[k], JcL[k * NC3 + c], AC[c]);
+                    for (int c = 0; c < NC3; c++) XC[c] = fmaf(ub[k], JcL[k * NC3 + c], XC[c]);
             }
             // (iii) full descent: joint accelerations of every link for this row's impulse
             Sv acur = ab, slot[NSL > 0 ? NSL : 1];
@@ -819,7 +853,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const int d = (int)((inf >> 8) & 0xffu);
                 float Y = 0.f;
                 switch (d) { HG_Y_CASES default: break; }
-                if (two_body) { if ((myanc2 >> i) & 1ull) Y += Yd2L[(d - 1) * NC3 + col]; }      // myanc2 != 0 only on contact-row lanes
+                if (R.two_body) { if ((R.myanc2 >> i) & 1ull) Y += Yd2L[(d - 1) * NC3 + col]; }      // myanc2 != 0 only on contact-row lanes
                 const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
                 a = sfma(ldsv(pc + 20), qa, a);
                 acur = a;
@@ -828,18 +862,27 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                     for (int s = 0; s < NSL; s++) if (sv == s) slot[s] = a;
                 }
-                if constexpr (NMX <= 16) AM0[i] = qa;
-                else if constexpr (NMX <= 32) { if (i < 16) AM0[i] = qa; else AM1[i - 16] = qa; }
-                else { if (i < 16) AM0[i] = qa; else if (i < 32) AM1[i - 16] = qa; else AM2[i - 32] = qa; }
-                if (i == body && (row_motor || row_slot)) diag = unit_f * qa;
+                if constexpr (NMX <= 16) XM0[i] = qa;
+                else if constexpr (NMX <= 32) { if (i < 16) XM0[i] = qa; else XM1[i - 16] = qa; }
+                else if constexpr (NMX <= 48) { if (i < 16) XM0[i] = qa; else if (i < 32) XM1[i - 16] = qa; else XM2[i - 32] = qa; }
+                else { if (i < 16) XM0[i] = qa; else if (i < 32) XM1[i - 16] = qa; else if (i < 48) XM2[i - 32] = qa; else XM3[i - 48] = qa; }
+                if (i == body && unit_row) xdiag = R.unit_f * qa;
                 if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) AC[c] = fmaf(qa, jr[c], AC[c]);
-                    if (col >= 0) diag = fmaf(qa, jr[col], diag);
+                    for (int c = 0; c < NC3; c++) XC[c] = fmaf(qa, jr[c], XC[c]);
+                    if (col >= 0) xdiag = fmaf(qa, jr[col], xdiag);
                 }
             }
-        }
+        };
+        // DUAL: the contact rows (row set 1) first -- their set-up values die here -- then the motor rows
+        if constexpr (DUAL) { if (nc > 0) response(R1, BM0, BM1, BM2, BM3, BC, diagB); }
+        response(R0, AM0, AM1, AM2, AM3, AC, diag);
+        const bool row_motor = R0.motor, row_slot = R0.slot;
+        const bool row_contact = DUAL ? false : R0.contact;      // set-0 view (one row per lane): the solver below
+        const int col = DUAL ? -1 : R0.col;
+        const float target_err = R0.target_err;
+        const bool row_active = row_motor || row_contact || row_slot;
 
         HG_TICK(8);
         // The SIMD's instruction arbiter serves its resident waves in strict order: equal user priority ->
@@ -868,16 +911,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             for (int k = 0; k < NMX; k++) {
                 if (k < 16) AM0[k] = (k == lane) ? 0.f : -AM0[k] * dinv;
                 else if (k < 32) AM1[k - 16] = (k == lane) ? 0.f : -AM1[k - 16] * dinv;
-                else AM2[k - 32] = (k == lane) ? 0.f : -AM2[k - 32] * dinv;
+                else if (k < 48) AM2[k - 32] = (k == lane) ? 0.f : -AM2[k - 32] * dinv;
+                else AM3[k - 48] = (k == lane) ? 0.f : -AM3[k - 48] * dinv;
             }
 #pragma unroll
-            for (int k = 0; k < NC3; k++) AC[k] = (NMX + k == lane) ? 0.f : -AC[k] * dinv;
+            for (int k = 0; k < NC3; k++) AC[k] = (!DUAL && NMX + k == lane) ? 0.f : -AC[k] * dinv;
             if (row_motor) { hi = cacheL[CACHE * lane + 27]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
             lim_b *= dinv;          // start value of the limit row's candidate: b_l / A_ii
         }
         float lam_l = 0.f;
+        float lam = 0.f;            // impulse of this lane's (set-0) row once the sweeps are done
 
+        if constexpr (!DUAL) {
         // The slot rows bring one more column each: aL[k][j] = -A[j][L_k] / A[j][j] = slot_sign * (column i_k),
         // except on the joint's own motor lane (-slot_sign: same Jacobian entry, A[i][L] = sign * A[i][i]) and on
         // the slot lane itself (0, the diagonal).
@@ -1035,11 +1081,130 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             if (P.iters & 1) sweep_limits(false);
         }
         HG_TICK(9);
-        float lam = 0.f;
 #pragma unroll
         for (int k = 0; k < NROWS; k++)       // lane k <- lam_k: one v_mov under a one-lane EXEC (all 64 lanes are active here)
             asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
                          : "+v"(lam) : "s"(slam[k]), "i"(k < 32 ? (int)(1u << (k & 31)) : 0), "i"(k >= 32 ? (int)(1u << (k & 31)) : 0));
+        if constexpr (KL > 0) {
+            if (use_slots) {
+#pragma unroll
+                for (int k = 0; k < KL; k++)
+                    if (k < nlim && lane == slot_joint[k]) lam_l = __int_as_float(slamL[k]);
+            }
+        }
+        lamL[lane] = fmaf(lim_s, lam_l, lam);      // joint impulse = motor row + (signed) limit row; contact lanes: their own impulse
+        } else {
+        // ---- 4b, two rows per lane.  The impulses live in VGPRs (lane i of lamv0: motor i, lane c of lamv1: contact
+        // row c; 66-98 of them would not fit the scalar register file), and a row update broadcasts the CHANGE of its impulse:
+        //   cand = med3(z, lo, hi);  d = cand - lam;  s_d = readlane(d, i);  z0 += A0_i s_d;  z1 += A1_i s_d;  lam_i = cand
+        // Same iterates, same row order.  Violated joint limits always take the run-time loop (a limit row lives on its
+        // joint's motor lane, see the one-row-per-lane solver above for the algebra).
+        float z1, lo1 = 0.f, hi1 = 0.f;
+        {
+            const float dinvB = (R1.contact && diagB > 1e-20f) ? __frcp_rn(diagB) : 0.f;
+            z1 = R1.target_err * dinvB;
+#pragma unroll
+            for (int k = 0; k < NMX; k++) {
+                if (k < 16) BM0[k] = -BM0[k] * dinvB;
+                else if (k < 32) BM1[k - 16] = -BM1[k - 16] * dinvB;
+                else if (k < 48) BM2[k - 32] = -BM2[k - 32] * dinvB;
+                else BM3[k - 48] = -BM3[k - 48] * dinvB;
+            }
+#pragma unroll
+            for (int k = 0; k < NC3; k++) BC[k] = (k == lane) ? 0.f : -BC[k] * dinvB;
+            if (R1.contact && R1.col < MAXC) { lo1 = 0.f; hi1 = 1e10f; }
+        }
+        float lamv0 = 0.f, lamv1 = 0.f;
+        float mu_s = P.mu;
+        asm volatile("" : "+s"(mu_s));
+        float mu_v = mu_s;
+        asm volatile("" : "+v"(mu_v));
+        const float lim_k = lim_b - lim_s * z;      // z is still b_m / A_ii here
+        auto colA = [&](const int i) -> float {     // compile-time i
+            if (i < 16) return AM0[i < 16 ? i : 0];
+            else if (i < 32) return AM1[i >= 16 && i < 32 && i < NMX ? i - 16 : 0];
+            else if (i < 48) return AM2[i >= 32 && i < 48 && i < NMX ? i - 32 : 0];
+            else return AM3[i >= 48 && i < NMX ? i - 48 : 0];
+        };
+        auto colB = [&](const int i) -> float {
+            if (i < 16) return BM0[i < 16 ? i : 0];
+            else if (i < 32) return BM1[i >= 16 && i < 32 && i < NMX ? i - 16 : 0];
+            else if (i < 48) return BM2[i >= 32 && i < 48 && i < NMX ? i - 32 : 0];
+            else return BM3[i >= 48 && i < NMX ? i - 48 : 0];
+        };
+        auto motor_update = [&](const int i) {
+            const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
+            const float s_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lamv0), i));
+            z = fmaf(colA(i), s_d, z);
+            if (nc > 0) z1 = fmaf(colB(i), s_d, z1);
+            asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
+                         : "+v"(lamv0) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
+        };
+        auto contact_update = [&](const int c, const float rlo, const float rhi) {       // contact row c: lane c of row set 1
+            const float cand = __builtin_amdgcn_fmed3f(z1, rlo, rhi);
+            const float s_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lamv1), c));
+            z = fmaf(AC[c], s_d, z);
+            z1 = fmaf(BC[c], s_d, z1);
+            asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
+                         : "+v"(lamv1) : "v"(cand), "i"(c < 32 ? (int)(1u << (c & 31)) : 0), "i"(c >= 32 ? (int)(1u << (c & 31)) : 0));
+        };
+        auto contact_rows = [&]() {
+            if (nc > 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) contact_update(c, lo1, hi1);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) {
+                        const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lamv1), c);
+                        if (tot_i > 0) {                      // tot > 0 on the scalar unit (positive float bits)
+                            const float lim = mu_v * __int_as_float(tot_i);
+                            contact_update(MAXC + 2 * c, -lim, lim);
+                            contact_update(MAXC + 2 * c + 1, -lim, lim);
+                        }
+                    }
+            }
+        };
+        auto limit_update = [&](const int i) {             // i: wave-uniform, known at run time
+            const float zl = lam_l + lim_k + lim_s * (z - lamv0);
+            const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), i));
+            const int j = i & 15;
+            float a_i, b_i;
+            if (i < 16) { a_i = AM0[j % clamp16(NMX)]; b_i = BM0[j % clamp16(NMX)]; }
+            else if (i < 32) { a_i = AM1[j % clamp16(NMX - 16)]; b_i = BM1[j % clamp16(NMX - 16)]; }
+            else if (i < 48) { a_i = AM2[j % clamp16(NMX - 32)]; b_i = BM2[j % clamp16(NMX - 32)]; }
+            else { a_i = AM3[j % clamp16(NMX - 48)]; b_i = BM3[j % clamp16(NMX - 48)]; }
+            z = fmaf(a_i, d, z);                            // a_ii = 0: lane i is handled next
+            z1 = fmaf(b_i, d, z1);
+            if (lane == i) { lam_l = cand; z -= d; }
+        };
+        auto sweep2 = [&](const bool forward) {
+            if (forward) {
+                #pragma unroll 1
+                for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update(__builtin_ctzll(mk));
+#pragma unroll
+                for (int i = 0; i < NMX; ++i) motor_update(i);
+            } else {
+#pragma unroll
+                for (int i = NMX - 1; i >= 0; --i) motor_update(i);
+                #pragma unroll 1
+                for (unsigned long long mk = limmask; mk != 0ull;) {
+                    const int i = 63 - __builtin_clzll(mk);
+                    limit_update(i);
+                    mk &= ~(1ull << i);
+                }
+            }
+            contact_rows();
+        };
+        #pragma unroll 1
+        for (int it = 0; it + 1 < P.iters; it += 2) { sweep2(false); sweep2(true); }
+        if (P.iters & 1) sweep2(false);
+        HG_TICK(9);
+        lam = lamv0;
+        lamL[lane] = fmaf(lim_s, lam_l, lamv0);      // joint impulse = motor row + (signed) limit row
+        if (lane < NC3) lamL[WAVE + lane] = lamv1;   // contact impulses
+        }
 
         {   // getJointState()[3]: the motor torque applied in this physics step (dancer_env.py:24)
             int lane_t = lane;
@@ -1048,26 +1213,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
-        if constexpr (KL > 0) {
-            if (use_slots) {
-#pragma unroll
-                for (int k = 0; k < KL; k++)
-                    if (k < nlim && lane == slot_joint[k]) lam_l = __int_as_float(slamL[k]);
-            }
-        }
-        lamL[lane] = fmaf(lim_s, lam_l, lam);      // joint impulse = motor row + (signed) limit row
         wave_sync();      // all reads of Jc by other lanes' Arow accumulation are done as well
         V3 bang = ld3(velL), bvel = ld3(velL + 3), bpos = ld3(baseL + 9);
         float bq[4] = {baseL[48], baseL[49], baseL[50], baseL[51]};
         wave_sync();      // F overwrites the velocity vector below
-        if (lane < ndof) {
-            float f = lane >= 6 ? lamL[lane - 6] : 0.f;
+        #pragma unroll 1
+        for (int k = lane; k < ndof; k += WAVE) {      // ndof = 6 + n may exceed the 64 lanes
+            float f = k >= 6 ? lamL[k - 6] : 0.f;
             if (nc > 0) {
-                const float *jr = JcL + lane * NC3;
+                const float *jr = JcL + k * NC3;
 #pragma unroll
-                for (int c = 0; c < NC3; c++) f = fmaf(jr[c], lamL[NMX + c], f);
+                for (int c = 0; c < NC3; c++) f = fmaf(jr[c], lamL[CBL + c], f);
             }
-            FL[lane] = f;
+            FL[k] = f;
         }
         wave_sync();      // Jc is dead: region AB is reused for the 6-float exchanges below
         {

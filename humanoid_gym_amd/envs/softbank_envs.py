@@ -23,8 +23,11 @@ class _SoftbankEnv(BatchedHumanoidEnv):
     ROBOT = ""
 
     def __init__(self, n_envs: int = 1, device=None, urdf_path=None, n_substeps: int = 1,
-                 auto_reset: bool = False, **cfg_overrides):
-        model, cfg = load_robot(self.ROBOT, urdf_path)
+                 auto_reset: bool = False, hands: bool = False, **cfg_overrides):
+        """hands=True (nao, romeo): the model with the finger / thumb joints of the hands as simulated dofs, as in
+        qibullet's URDFs (42 / 61 dofs; two constraint rows per lane in the kernel).  They follow LHand / RHand
+        through their <mimic> tags; the controlled joint lists are unchanged (romeo_env.py:24-26)."""
+        model, cfg = load_robot(self.ROBOT, urdf_path, hands=hands)
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)
         super().__init__(model, cfg, n_envs, device, n_substeps, auto_reset)

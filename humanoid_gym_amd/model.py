@@ -17,11 +17,11 @@ from typing import Dict, List
 
 import numpy as np
 
-HG_MAX_LINKS = 48
+HG_MAX_LINKS = 62
 HG_MAX_SPHERES = 192
 HG_MAX_PAIRS = 1024
 HG_MAX_CONTACTS = 12
-HG_MAX_ROWS = 64
+HG_MAX_ROWS = 128
 HG_STATE_BASE = 13
 
 SPHERE_GROUND = 1

@@ -52,8 +52,12 @@ def softbank_config(**kw) -> SimConfig:
     return c
 
 
-def load_robot(name: str, urdf_path: Optional[str] = None) -> Tuple[FlatModel, SimConfig]:
+def load_robot(name: str, urdf_path: Optional[str] = None, hands: bool = False) -> Tuple[FlatModel, SimConfig]:
+    """name: dancer | nao | pepper | romeo; "nao_hands" / "romeo_hands" (or hands=True) select the stand-ins
+    that include the finger joints of the hands (42 / 61 dofs)."""
     name = name.lower()
+    if name.endswith("_hands"):
+        name, hands = name[:-len("_hands")], True
     if name == "dancer":
         if urdf_path:
             m = load_urdf(urdf_path, base_position=[-0.3, -0.3, 0.3],
@@ -64,5 +68,5 @@ def load_robot(name: str, urdf_path: Optional[str] = None) -> Tuple[FlatModel, S
         return m, dancer_config()
     if name in ("nao", "pepper", "romeo"):
         from .softbank_like import load_softbank_like
-        return load_softbank_like(name, urdf_path), softbank_config()
+        return load_softbank_like(name, urdf_path, hands=hands), softbank_config()
     raise KeyError(f"unknown robot {name!r}")

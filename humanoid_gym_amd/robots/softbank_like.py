@@ -58,12 +58,22 @@ def _lowest_point(m: FlatModel) -> float:
     return float(lo)
 
 
-def load_softbank_like(name: str, urdf_path: Optional[str] = None) -> FlatModel:
+def load_softbank_like(name: str, urdf_path: Optional[str] = None, hands: bool = False) -> FlatModel:
+    """hands=True (nao, romeo): the stand-in that also has the finger / thumb joints of SoftBank's hands --
+    they are simulated dofs of the reference's robots (romeo_env.py:24-26 filters them out of the CONTROLLED
+    set only), 16 for NAO (42 dofs in all), 24 for Romeo (61)."""
     from . import NAO_JOINTS, PEPPER_JOINTS
     posture = {"nao": NAO_STAND, "pepper": PEPPER_STAND, "romeo": ROMEO_STAND}[name]
-    path = urdf_path or os.path.join(_HERE, f"{name}_like.urdf")
+    if hands and name not in ("nao", "romeo"):
+        raise KeyError(f"no hands variant of {name!r}")
+    path = urdf_path or os.path.join(_HERE, f"{name}_hands_like.urdf" if hands else f"{name}_like.urdf")
     probe = load_urdf(path, name=name)
     q_init = {k: v for k, v in posture.items() if k in probe.joint2Index}
+    # <mimic> joints start where the joint they follow puts them (qibullet drives them together)
+    for child, (parent, mult, off) in (probe.meta.get("mimic") or {}).items():
+        if child in probe.joint2Index and child not in q_init:
+            k = probe.dof_of(child)
+            q_init[child] = float(np.clip(mult * q_init.get(parent, 0.0) + off, probe.lower[k], probe.upper[k]))
     m = load_urdf(path, base_position=(0, 0, 0), q_init=q_init, self_collision=True,
                   default_max_force=100000.0, name=name)
     # spawn like qibullet does: upright at the origin, soles 1 mm above the ground plane

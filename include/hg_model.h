@@ -28,11 +28,11 @@
 extern "C" {
 #endif
 
-#define HG_MAX_LINKS    48   /* moving links == joint dofs                         */
+#define HG_MAX_LINKS    62   /* moving links == joint dofs (one lane each, plus the base; 64-bit link masks) */
 #define HG_MAX_SPHERES  192  /* collision spheres (radius may be 0 = point)        */
 #define HG_MAX_PAIRS    1024 /* self-collision sphere pairs                        */
 #define HG_MAX_CONTACTS 12   /* contact slots per env per physics step             */
-#define HG_MAX_ROWS     64   /* n_links + 3*max_contacts must not exceed this      */
+#define HG_MAX_ROWS     128  /* n_links + 3*max_contacts: one row per lane up to 64, two per lane beyond   */
 
 typedef struct hg_model {
     int32_t n_links;                       /* n: moving links / dofs                */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_capi.SYMBOLS)
     for n in names:
         assert getattr(L, n) is not None
-    assert L.hg_abi_version() == 4
+    assert L.hg_abi_version() == 5
 
 
 def test_struct_sizes_match_header():

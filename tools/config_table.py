@@ -37,8 +37,10 @@ if __name__ == "__main__":
     # enable_self=False rows are there to show what the pair table costs
     run("nao", 4096, seed=0)
     run("nao", 4096, seed=0, enable_self=False)
+    run("nao_hands", 4096, seed=0)                       # 42 dofs: the finger joints of the hands are simulated dofs
     run("pepper", 16384, seed=2)
     run("romeo", 8192, seed=3)
     run("romeo", 8192, seed=3, enable_self=False)
+    run("romeo_hands", 8192, seed=3)                     # 61 dofs
     run("dancer", 65536, n_substeps=4, seed=4)
     run("dancer", 65536, n_substeps=4, seed=4, enable_self=False)

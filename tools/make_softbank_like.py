@@ -60,6 +60,14 @@ class Urdf:
         s += [f'    <dynamics damping="{damping:.6g}" friction="0"/>', '  </joint>']
         self.joints.append("\n".join(s))
 
+    def mimic_joint(self, name, parent, child, xyz, axis, lower, upper, mimic, multiplier=1.0, offset=0.0,
+                    effort=0.3, velocity=8.3):
+        """revolute joint that carries a <mimic> tag: Bullet simulates it as an ordinary dof, qibullet's
+        setAngles drives it from the joint it mimics (the finger joints of the SoftBank hands)."""
+        self.joint(name, parent, child, xyz, axis, lower, upper, effort, velocity)
+        self.joints[-1] = self.joints[-1].replace(
+            "  </joint>", f'    <mimic joint="{mimic}" multiplier="{multiplier:.6g}" offset="{offset:.6g}"/>\n  </joint>')
+
     def write(self, path, comment):
         with open(path, "w") as f:
             f.write('<?xml version="1.0"?>\n<!-- ' + comment + ' -->\n')
@@ -73,8 +81,31 @@ X, Y, Z = (1, 0, 0), (0, 1, 0), (0, 0, 1)
 S2 = 0.70710678118
 
 
-def make_nao():
-    u = Urdf("nao_like")
+def add_hand(u, side, chains, phalanx=0.014, mass=0.002):
+    """Finger joints of one hand, hanging off the `<side>_gripper` link and mimicking `<Side>Hand`.
+    chains: {"Finger1": 3, "Finger2": 3, "Thumb": 2} -> LFinger11..13, LFinger21..23, LThumb1..2: the joint
+    names of SoftBank's hands [public documentation / upstream recall]; dimensions and masses are approximate
+    (light phalanges, a few grams).  Fingers curl about y, the thumb about z; no collision geometry."""
+    S, s = side, side.lower()
+    for ci, (chain, count) in enumerate(chains.items()):
+        parent = f"{s}_gripper"
+        yoff = (ci - 0.5 * (len(chains) - 1)) * 0.012
+        for k in range(1, count + 1):
+            jn = f"{S}{chain}{k}"
+            ln = f"{jn}_link"
+            u.link(ln, mass, (0.5 * phalanx, 0, 0), (phalanx, 0.008, 0.008))
+            xyz = (0.02, yoff, 0.0) if k == 1 else (phalanx, 0, 0)
+            axis = Z if chain.startswith("Thumb") else Y
+            u.mimic_joint(jn, parent, ln, xyz, axis, 0.0, 1.0, f"{S}Hand", multiplier=0.95, offset=0.0)
+            parent = ln
+
+
+NAO_HAND = {"Finger1": 3, "Finger2": 3, "Thumb": 2}                    # 8 joints per hand, 16 in all: 26 + 16 = 42 dofs
+ROMEO_HAND = {"Finger1": 3, "Finger2": 3, "Finger3": 3, "Thumb": 3}    # 12 per hand, 24 in all: 37 + 24 = 61 dofs
+
+
+def make_nao(hands=False):
+    u = Urdf("nao_hands_like" if hands else "nao_like")
     u.link("torso", 1.05, (-0.004, 0, 0.043), (0.10, 0.13, 0.19), ("box", (0.10, 0.13, 0.19)))
     # head
     u.link("Neck", 0.064, (0, 0, -0.027), (0.03, 0.03, 0.05))
@@ -123,8 +154,11 @@ def make_nao():
         u.joint(f"{side}ElbowRoll", f"{side}Elbow", f"{side}ForeArm", (0, 0, 0), Z, *lim["ElbowRoll"], 1.33, 7.19)
         u.joint(f"{side}WristYaw", f"{side}ForeArm", f"{side.lower()}_wrist", (0.05595, 0, 0), X, *lim["WristYaw"], 0.85, 24.6)
         u.joint(f"{side}Hand", f"{side.lower()}_wrist", f"{side.lower()}_gripper", (0.05775, 0, -0.012), X, *lim["Hand"], 0.3, 8.3)
-    u.write(os.path.join(OUT, "nao_like.urdf"),
-            "NAO-like stand-in authored for humanoid_gym_amd; NOT SoftBank's URDF (see robots/__init__.py)")
+        if hands:
+            add_hand(u, side, NAO_HAND)
+    u.write(os.path.join(OUT, "nao_hands_like.urdf" if hands else "nao_like.urdf"),
+            "NAO-like stand-in" + (" WITH the 16 finger joints of the hands (42 dofs)" if hands else "") +
+            " authored for humanoid_gym_amd; NOT SoftBank's URDF (see robots/__init__.py)")
 
 
 def make_pepper():
@@ -168,8 +202,8 @@ def make_pepper():
             "Pepper-like stand-in authored for humanoid_gym_amd; NOT SoftBank's URDF (see robots/__init__.py)")
 
 
-def make_romeo():
-    u = Urdf("romeo_like")
+def make_romeo(hands=False):
+    u = Urdf("romeo_hands_like" if hands else "romeo_like")
     u.link("torso", 9.0, (0, 0, 0.12), (0.20, 0.30, 0.38), ("box", (0.18, 0.28, 0.36)), (0, 0, 0.12))
     # neck / head / eyes
     u.link("NeckYawLink", 0.3, (0, 0, 0.02), (0.05, 0.05, 0.05))
@@ -224,12 +258,17 @@ def make_romeo():
         u.joint(f"{side}WristYaw", f"{side}WristRollLink", f"{side}WristYawLink", (0, 0, 0), Z, -0.5236, 0.5236, 3.0, 8.0)
         u.joint(f"{side}WristPitch", f"{side}WristYawLink", f"{side.lower()}_wrist", (0, 0, 0), Y, -1.0123, 0.9948, 3.0, 8.0)
         u.joint(f"{side}Hand", f"{side.lower()}_wrist", f"{side.lower()}_gripper", (0.08, 0, -0.02), X, 0.0, 1.0, 0.5, 8.0)
-    u.write(os.path.join(OUT, "romeo_like.urdf"),
-            "Romeo-like stand-in authored for humanoid_gym_amd; NOT SoftBank's URDF (see robots/__init__.py)")
+        if hands:
+            add_hand(u, side, ROMEO_HAND, phalanx=0.025, mass=0.006)
+    u.write(os.path.join(OUT, "romeo_hands_like.urdf" if hands else "romeo_like.urdf"),
+            "Romeo-like stand-in" + (" WITH the 24 Finger/Thumb joints of the hands (61 dofs)" if hands else "") +
+            " authored for humanoid_gym_amd; NOT SoftBank's URDF (see robots/__init__.py)")
 
 
 if __name__ == "__main__":
     make_nao()
+    make_nao(hands=True)
     make_pepper()
     make_romeo()
-    print("wrote nao_like.urdf pepper_like.urdf romeo_like.urdf to", OUT)
+    make_romeo(hands=True)
+    print("wrote nao_like.urdf nao_hands_like.urdf pepper_like.urdf romeo_like.urdf romeo_hands_like.urdf to", OUT)
