@@ -265,17 +265,18 @@ namespace hg {
 // kernel instantiations: motor lanes, contact slots, tree depth, branch slots, waves per SIMD
 struct Variant { int nmx, maxc, depth, nsl, wpe; };
 #define HG_VARIANTS(X) \
-    X(0, 18, 12, 6, 0, 4)  /* dancer                                   */ \
+    X(0, 18, 12, 6, 0, 4)  /* dancer (3 waves/SIMD would need no scratch but is 18 % slower) */ \
     X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
     X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
     X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
-    X(4, 20, 8, 12, 2, 4)  /* pepper (deep chain, branching torso)     */ \
-    X(5, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
-    X(6, 37, 8, 12, 2, 3)  /* romeo: 61 rows, 3 lanes left for limits  */ \
-    X(7, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
-    X(8, 46, 6, 12, 2, 3)  /* anything up to 46 dofs, 6 contacts       */ \
-    X(9, 44, 8, 12, 2, 2)  /* nao with finger joints (42 dofs): 68 rows, two rows per lane */ \
-    X(10, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows            */
+    X(4, 20, 8, 9, 2, 4)   /* pepper (deep chain, branching torso)     */ \
+    X(5, 20, 8, 12, 2, 4)  /* 20 dofs, deeper chains                   */ \
+    X(6, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
+    X(7, 37, 8, 12, 2, 3)  /* romeo: 61 rows, 3 lanes left for limits  */ \
+    X(8, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
+    X(9, 46, 6, 12, 2, 3)  /* anything up to 46 dofs, 6 contacts       */ \
+    X(10, 44, 8, 12, 2, 2) /* nao with finger joints (42 dofs): 68 rows, two rows per lane */ \
+    X(11, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows            */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -477,6 +478,11 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     for (int v = 0; v < kNumVariants; v++)
         if (kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts &&
             kVariants[v].depth >= hm->maxlev && kVariants[v].nsl >= hm->n_slots) { variant = v; break; }
+    if (const char *ov = getenv("HG_VARIANT")) {      // diagnostics: force an instantiation that fits the model (tools/config_table.py)
+        const int v = atoi(ov);
+        if (v >= 0 && v < kNumVariants && kVariants[v].nmx >= n && kVariants[v].maxc >= config->max_contacts &&
+            kVariants[v].depth >= hm->maxlev && kVariants[v].nsl >= hm->n_slots) variant = v;
+    }
     if (variant < 0) {
         delete hm;
         return fail(HG_EUNSUPPORTED, "hg_create: no kernel variant for this (n_links, max_contacts, tree depth, branching)");

@@ -8,7 +8,11 @@ does (same URDF, spawn pose, flags, gravity, iterations, time step) and compares
   * the free-fall + position-control phase before the first ground contact: joint angles
     within 1e-4 rad, base height within 1e-4 m (north_star tolerance);
   * after landing: bounded drift only (the collision geometry differs by construction:
-    mesh hulls there, bounding boxes here).
+    mesh hulls there, hull support vertices + inscribed spheres here).
+Both the FP64 oracle AND, when a GPU is visible, the product library (libhg_sim.so through the C-ABI) are
+stepped beside PyBullet, so the first box that has PyBullet pins the oracle and the kernel in one run.
+With qibullet importable as well, nao-v0 is compared the same way (nao_env.py:20,36-42,70-73): joint
+names / limits / Stand posture from qibullet's own NAO description, then a contact-free replay.
 """
 import os
 
@@ -49,17 +53,143 @@ def test_index_maps_equal_pybullet(bullet):
     assert parents == model.parent.tolist()
 
 
+def _gpu_sim(model, cfg, n_envs=1):
+    """The product path (libhg_sim.so through the C-ABI) when a GPU is visible, else None."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None, None
+        from humanoid_gym_amd._capi import HgSim
+        return HgSim(model, cfg, n_envs, "cuda:0"), torch
+    except Exception:           # no library / no device: the oracle alone is compared
+        return None, None
+
+
 def test_contact_free_phase_matches_pybullet(bullet):
     model, cfg = load_robot("dancer", URDF)
     sim = OracleSim(model, cfg, 1)
+    gpu, torch = _gpu_sim(model, cfg)
     rng = np.random.default_rng(4)
     act = rng.uniform(-0.3, 0.3, 18)
+    act[7], act[13] = -0.3, 0.3               # spread the hips: the feet touch each other at q = 0 (self-collision is on)
     idx = list(range(18))
     for t in range(14):                       # first ground contact is around step 20
         p.setJointMotorControlArray(bullet, idx, p.POSITION_CONTROL, act.tolist())
         p.stepSimulation()
         o = sim.step(act[None])
         q_ref = np.array([p.getJointState(bullet, i)[0] for i in idx])
+        tau_ref = np.array([p.getJointState(bullet, i)[3] for i in idx])
         assert np.abs(o["q"][0] - q_ref).max() < 1e-4, t
+        assert np.abs(o["motor_torque"][0] - tau_ref).max() < 1e-3 * max(1.0, np.abs(tau_ref).max()), t
+        if gpu is not None:
+            gq = gpu.step(torch.tensor(act[None], dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
+            assert np.abs(gq[0] - q_ref).max() < 1e-4, ("libhg_sim.so", t)
     pos, _ = p.getBasePositionAndOrientation(bullet)
     assert abs(pos[2] - sim.state[0, 2]) < 1e-4
+    if gpu is not None:
+        # base position reported by PyBullet is the COM of the base link, like the state record's
+        assert abs(pos[2] - float(gpu.get_state()[0, 2])) < 1e-4
+
+
+def test_contact_flags_and_drift_after_landing(bullet):
+    """dancer_env.py:32-39: `collision` (any non-base link in contact, ground included) and the self-pair link
+    indices, once the robot stands; joint angles and base height only within a bounded drift (different
+    collision geometry by construction)."""
+    model, cfg = load_robot("dancer", URDF)
+    sim = OracleSim(model, cfg, 1)
+    gpu, torch = _gpu_sim(model, cfg)
+    act = np.zeros(18)
+    act[7], act[13] = -0.05, 0.05             # dancer_env.py:84
+    idx = list(range(18))
+    for t in range(240):
+        p.setJointMotorControlArray(bullet, idx, p.POSITION_CONTROL, act.tolist())
+        p.stepSimulation()
+        o = sim.step(act[None])
+        if gpu is not None:
+            gpu.step(torch.tensor(act[None], dtype=torch.float32, device="cuda:0"))
+    ref_col = any(len(p.getContactPoints(bodyA=bullet, linkIndexA=i)) > 0 for i in idx)          # dancer_env.py:33-35
+    ref_links = sorted({i for i in idx if len(p.getContactPoints(bodyA=bullet, linkIndexA=i)) > 0})
+    assert bool(o["collision"][0]) == ref_col
+    ours = sorted({b for b in range(18) if (int(o["link_mask"][0]) >> (b + 1)) & 1})
+    assert ours == ref_links, (ours, ref_links)                                                    # link-level contact set
+    q_ref = np.array([p.getJointState(bullet, i)[0] for i in idx])
+    pos, _ = p.getBasePositionAndOrientation(bullet)
+    assert np.abs(o["q"][0] - q_ref).max() < 2e-2 and abs(pos[2] - sim.state[0, 2]) < 5e-3         # bounded drift
+    if gpu is not None:
+        assert bool(gpu.collision[0].item()) == ref_col
+        st = gpu.get_state()[0].cpu().numpy()
+        assert np.abs(st[13:31] - q_ref).max() < 2e-2 and abs(pos[2] - st[2]) < 5e-3
+
+
+# ---- nao-v0 through qibullet (nao_env.py:17-46, 70-73) ------------------------------------------------
+def _qibullet_nao():
+    qibullet = pytest.importorskip("qibullet")
+    mgr = qibullet.SimulationManager()
+    client = mgr.launchSimulation(gui=False, auto_step=False)          # DIRECT, explicit stepping (SURVEY 3c)
+    robot = mgr.spawnNao(client, spawn_ground_plane=True)               # nao_env.py:20
+    return qibullet, mgr, client, robot
+
+
+def test_nao_layout_equals_qibullet():
+    qibullet, mgr, client, robot = _qibullet_nao()
+    try:
+        urdf = getattr(robot, "description_file", None)
+        if not urdf or not os.path.exists(urdf):
+            pytest.skip("qibullet does not expose the NAO description file on this version")
+        from humanoid_gym_amd.robots import NAO_JOINTS
+        model, cfg = load_robot("nao", urdf)
+        for k, name in enumerate(NAO_JOINTS):                                     # nao_env.py:35-38
+            j = robot.joint_dict[name]
+            d = model.act_joint[k]
+            assert model.dof_names[d] == name
+            assert abs(model.lower[d] - j.getLowerLimit()) < 1e-9 and abs(model.upper[d] - j.getUpperLimit()) < 1e-9
+            assert model.joint2Index[name] == j.getIndex()                         # PyBullet joint index
+        n_fingers = sum(1 for n in robot.joint_dict if "Finger" in n or "Thumb" in n)
+        assert sum(1 for n in model.dof_names if "Finger" in n or "Thumb" in n) == n_fingers   # simulated dofs, not controlled
+        posture = qibullet.NaoPosture("Stand")                                     # nao_env.py:24-27
+        ref = dict(zip(posture.joint_names, posture.joint_values))
+        from humanoid_gym_amd.robots.softbank_like import NAO_STAND
+        worst = max(abs(NAO_STAND[n] - v) for n, v in ref.items() if n in NAO_STAND)
+        print(f"[pybullet-optin] Stand posture table differs from qibullet's by at most {worst:.3f} rad")
+    finally:
+        mgr.stopSimulation(client)
+
+
+def test_nao_contact_free_replay_matches_qibullet():
+    """setAngles(names, values, 1.0) + one stepSimulation per env step, gravity off and the robot lifted off the
+    ground so that the 1 s replay is contact-free: joint angles within 1e-4 rad (north_star)."""
+    qibullet, mgr, client, robot = _qibullet_nao()
+    try:
+        urdf = getattr(robot, "description_file", None)
+        if not urdf or not os.path.exists(urdf):
+            pytest.skip("qibullet does not expose the NAO description file on this version")
+        from humanoid_gym_amd.workloads import nao_replay_joints, pack_rows, synthetic_h5_trajectory
+        model, cfg = load_robot("nao", urdf)
+        cfg.gravity, cfg.enable_ground = (0.0, 0.0, 0.0), False
+        p.setGravity(0, 0, 0, physicsClientId=client)
+        uid = robot.getRobotModel()
+        pos, orn = p.getBasePositionAndOrientation(uid, physicsClientId=client)
+        p.resetBasePositionAndOrientation(uid, [pos[0], pos[1], pos[2] + 1.0], orn, physicsClientId=client)
+        sim = OracleSim(model, cfg, 1)
+        sim.state[0, 2] += 1.0
+        gpu, torch = _gpu_sim(model, cfg)
+        if gpu is not None:
+            gpu.set_state(torch.tensor(sim.state, dtype=torch.float32))
+        names = nao_replay_joints()
+        l, r = synthetic_h5_trajectory(model, T=240, seed=1234)
+        rows = pack_rows(l, r)
+        sel = np.array([model.dof_of(n) for n in names], np.int32)
+        extra = [(model.dof_of(c), names.index(pa), m_, o_) for c, (pa, m_, o_) in model.meta["mimic"].items() if pa in names]
+        for t in range(240):
+            robot.setAngles(names, rows[t].tolist(), 1.0)                          # nao_env.py:70
+            p.stepSimulation(physicsClientId=client)
+            act = np.concatenate([rows[t], [m_ * rows[t][k] + o_ for _, k, m_, o_ in extra]])[None]
+            full_sel = np.concatenate([sel, [d for d, _, _, _ in extra]]).astype(np.int32)
+            o = sim.step(act, joint_sel=full_sel)
+            q_ref = np.array(robot.getAnglesPosition(model.dof_names[k] for k in model.act_joint))   # nao_env.py:73
+            assert np.abs(o["q"][0] - q_ref).max() < 1e-4, t
+            if gpu is not None:
+                gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=full_sel)[0].cpu().numpy()
+                assert np.abs(gq[0] - q_ref).max() < 1e-4, ("libhg_sim.so", t)
+    finally:
+        mgr.stopSimulation(client)
