@@ -49,6 +49,17 @@ def synthetic_replay(model, seed=1234):
     return rows.astype(np.float32), sel
 
 
+def with_mimic_columns(model, rows, sel, names):
+    """qibullet's setAngles drives the finger joints that <mimic> LHand / RHand together with them (the env layer
+    does the same, softbank_envs.py): one more action column per such joint, target = multiplier * hand + offset."""
+    cols, sel = [rows], list(sel)
+    for child, (parent, mult, off) in (model.meta.get("mimic") or {}).items():
+        if parent in names and child in model.dof_names:
+            sel.append(model.dof_of(child))
+            cols.append((mult * rows[:, names.index(parent)] + off)[:, None])
+    return np.concatenate(cols, axis=1).astype(np.float32), np.array(sel, np.int32)
+
+
 def algorithmic_bytes_per_env_step(model, n_sel):
     """actions + obs + reward + flags + state read and written once."""
     n = model.n_links
@@ -307,6 +318,36 @@ def main():
             pipelined = {"error": f"{type(e).__name__}: {e}"}
     finite = bool(torch.isfinite(sim.get_state()).all().item())
 
+    # Beside the headline as well: the same replay on the NAO stand-in that ALSO simulates the 16 finger joints of the
+    # hands (42 dofs, as qibullet's NAO has; 66 constraint rows = two rows per lane in the kernel), fingers following
+    # LHand / RHand through their mimic columns.
+    with_hands = None
+    if args.robot == "nao" and not args.cfg and os.environ.get("HG_BENCH_HANDS", "1") != "0":
+        try:
+            from humanoid_gym_amd.workloads import nao_replay_joints
+            hmodel, hcfg = load_robot("nao_hands")
+            hrows, hsel = synthetic_replay(hmodel)
+            hrows, hsel = with_mimic_columns(hmodel, hrows, hsel, nao_replay_joints())
+            hsim = HgSim(hmodel, hcfg, n_envs, dev)
+            hrows_d = torch.tensor(hrows, device=dev)
+            hact = torch.stack([hrows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
+            for t in range(args.warmup):
+                hsim.step(hact[t % T_TRAJ], joint_sel=hsel, n_substeps=1)
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            for t in range(args.warmup, args.warmup + args.steps):
+                hsim.step(hact[t % T_TRAJ], joint_sel=hsel, n_substeps=1)
+            torch.cuda.synchronize()
+            h_el = time.perf_counter() - h0
+            with_hands = {"robot": "nao_hands_like (stand-in URDF with the 16 finger joints)", "n_dof": hmodel.n_links,
+                          "constraint_rows": hmodel.n_links + 3 * hcfg.max_contacts, "action_columns": int(len(hsel)),
+                          "value_this_rank": n_envs * args.steps / h_el, "unit": "env-steps/s",
+                          "ms_per_step": h_el / args.steps * 1e3,
+                          "state_finite": bool(torch.isfinite(hsim.get_state()).all().item())}
+            hsim.close()
+        except Exception as e:      # noqa: BLE001
+            with_hands = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         total_envs = n_envs * world
         value = total_envs * args.steps / elapsed
@@ -349,6 +390,8 @@ def main():
         }
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if with_hands is not None:
+            out["nao_with_finger_joints"] = with_hands
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
         print(json.dumps(out))

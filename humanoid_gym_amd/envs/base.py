@@ -22,7 +22,9 @@ class BatchedHumanoidEnv(_EnvBase):
     With ``n_envs == 1`` (the reference's only mode) observations come back as
     plain Python lists / floats / bools exactly as the reference returns them;
     with ``n_envs > 1`` they are torch tensors with a leading env axis that
-    stay on the GPU.
+    stay on the GPU.  Those tensors (observations, reward, done, collision) are
+    the SAME buffers on every step -- the kernel writes them in place, nothing is
+    allocated per step -- so a rollout buffer must ``clone()`` what it keeps.
     """
 
     def __init__(self, model: FlatModel, cfg: SimConfig, n_envs: int = 1, device=None, n_substeps: int = 1,

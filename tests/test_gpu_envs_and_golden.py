@@ -401,3 +401,27 @@ def test_step_is_capturable_in_a_hip_graph():
     assert torch.equal(eager.get_state(), graphed.get_state())
     assert torch.equal(eager.obs_q, graphed.obs_q) and torch.equal(eager.done, graphed.done)
     eager.close(); graphed.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+    """The N > 1 path end to end with the real simulator: `bench.py --gpus 2` starts two ranks itself; on a
+    one-GPU box both bind cuda:0 (HG_BENCH_SINGLE_DEVICE) and the statistics all-reduce goes through gloo,
+    which EpisodeStats must stage through the host (device tensors: the branch that once hung).
+    RCCL itself needs one GPU per rank and is exercised by the driver's multi-GPU run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HG_BENCH_SINGLE_DEVICE="1", HG_BENCH_HANDS="0", HG_STATS_EVERY="4")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "12",
+                          "--warmup", "4", "--envs-per-gpu", "256", "--no-cpu-baseline", "--stream-groups", "0"],
+                         env=env, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["envs_per_gpu"] == 256 and rec["config"]["state_finite"]
+    assert rec["global_env_steps"] == 2 * 256 * (12 + 4)            # both ranks' counters arrived through the all-reduce
+    assert rec["value"] > 0 and rec["per_rank_ms_per_step"]["max"] >= rec["per_rank_ms_per_step"]["min"] > 0
