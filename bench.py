@@ -289,7 +289,7 @@ def main():
     # (humanoid_gym_amd/groups.py) -- the replay has no observation -> action dependency, so steps of
     # different groups may overlap; same work per step, statistics flushed at the same cadence.
     pipelined = None
-    if args.stream_groups > 1:
+    if args.stream_groups > 1 and world == 1:     # extras are measured on a single-GPU run only
         try:          # an extra beside the headline: it must never take the bench line down with it
             from humanoid_gym_amd.groups import SimGroups
             grp = SimGroups(model, cfg, n_envs, args.stream_groups, dev)
@@ -322,7 +322,7 @@ def main():
     # hands (42 dofs, as qibullet's NAO has; 66 constraint rows = two rows per lane in the kernel), fingers following
     # LHand / RHand through their mimic columns.
     with_hands = None
-    if args.robot == "nao" and not args.cfg and os.environ.get("HG_BENCH_HANDS", "1") != "0":
+    if args.robot == "nao" and not args.cfg and world == 1 and os.environ.get("HG_BENCH_HANDS", "1") != "0":
         try:
             from humanoid_gym_amd.workloads import nao_replay_joints
             hmodel, hcfg = load_robot("nao_hands")

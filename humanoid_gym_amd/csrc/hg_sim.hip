@@ -276,7 +276,8 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
     X(8, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
     X(9, 46, 6, 12, 2, 3)  /* anything up to 46 dofs, 6 contacts       */ \
     X(10, 44, 8, 12, 2, 2) /* nao with finger joints (42 dofs): 68 rows, two rows per lane */ \
-    X(11, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows (1 wave/SIMD = no scratch, but 1.5x slower) */
+    X(11, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows (1 wave/SIMD = no scratch, but 1.5x slower) */ \
+    X(12, 62, 12, 12, 2, 2) /* catch-all: every model within the limits of hg_model.h has a kernel */
 #define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));

@@ -151,6 +151,7 @@ def test_hands_joint_limit_rows(name, n_violate):
     # interpenetrating boxes and a single step then differs by 3e-4 rad -- in the one-row-per-lane variant
     # (max_contacts=6) just the same, 0.04 rad there: conditioning of that state, not of a kernel variant.
     (dict(n_links=45, max_depth=9, n_chains=5, seed=23), dict(max_contacts=8, enable_self=True), 120),
+    (dict(n_links=40, max_depth=8, n_chains=6, seed=24), dict(max_contacts=12), 150),                                           # catch-all variant: 40 + 36 rows
 ])
 def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
     import torch

@@ -235,3 +235,41 @@ def test_welded_child_after_revolute_sibling_keeps_a_bodys_spheres_contiguous(tm
     assert rc in (0, -2), (rc, L.hg_last_error())           # accepted: 0 on a GPU box, "no device" here -- never HG_EINVAL
     if rc == 0:
         L.hg_destroy(h)
+
+
+def test_hands_variants_of_nao_and_romeo():
+    """romeo_env.py:24-26 filters Finger / Thumb joints out of the CONTROLLED set: they are simulated dofs of the
+    reference's robots.  hands=True / "<robot>_hands" load the stand-ins that have them; the env-facing joint lists
+    are unchanged, the fingers mimic LHand / RHand and start where the Stand posture puts the hands."""
+    import ctypes as C
+    from humanoid_gym_amd import _capi
+    nao, cfg = load_robot("nao_hands")
+    plain, _ = load_robot("nao")
+    assert nao.n_links == 42 and plain.n_links == 26
+    assert [nao.dof_names[k] for k in nao.act_joint] == NAO_JOINTS                     # nao_env.py:30-31
+    fingers = [n for n in nao.dof_names if "Finger" in n or "Thumb" in n]
+    assert len(fingers) == 16 and {"LFinger11", "LFinger23", "RThumb2"} <= set(fingers)
+    assert set(nao.meta["mimic"]) == set(fingers) and all(v[0] in ("LHand", "RHand") for v in nao.meta["mimic"].values())
+    assert abs(nao.q_init[nao.dof_of("LFinger11")] - 0.95 * nao.q_init[nao.dof_of("LHand")]) < 1e-12
+    assert nao.n_links + 3 * cfg.max_contacts == 66                                    # more rows than lanes
+    rom, _ = load_robot("romeo", hands=True)
+    assert rom.n_links == 61 and rom.n_act == 37
+    assert not any("Finger" in rom.dof_names[k] or "Thumb" in rom.dof_names[k] for k in rom.act_joint)
+    assert sum(1 for n in rom.dof_names if "Finger" in n or "Thumb" in n) == 24
+    with pytest.raises(KeyError):
+        load_robot("pepper", hands=True)
+    # the library accepts them on the host (a kernel variant exists); on this box it then finds no device
+    L = _capi.load_library()
+    h = C.c_void_p()
+    for m in (nao, rom):
+        cm, cc = m.to_c(), cfg.to_c()
+        assert L.hg_create(C.byref(cm), C.byref(cc), 4, 0, C.byref(h)) in (0, -2), L.hg_last_error()
+        if h.value:
+            L.hg_destroy(h)
+    cc = cfg.to_c(); cc.max_contacts = 12                                              # catch-all variant: 61 dofs, 12 contact slots
+    cm = rom.to_c()
+    assert L.hg_create(C.byref(cm), C.byref(cc), 4, 0, C.byref(h)) in (0, -2), L.hg_last_error()
+    if h.value:
+        L.hg_destroy(h)
+    cm.n_links = 63                                                                    # beyond HG_MAX_LINKS
+    assert L.hg_create(C.byref(cm), C.byref(cc), 4, 0, C.byref(h)) == -1 and b"n_links" in L.hg_last_error()
