@@ -1145,7 +1145,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
             const float s_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lamv0), i));
             z = fmaf(colA(i), s_d, z);
-            if (nc > 0) z1 = fmaf(colB(i), s_d, z1);
+            z1 = fmaf(colB(i), s_d, z1);      // unconditional: without contacts the B columns are all zero (a test per row costs a v_cndmask)
             asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
                          : "+v"(lamv0) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
         };

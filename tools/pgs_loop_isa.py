@@ -16,9 +16,11 @@ for s in starts:
         if m and m.group(1) in lab and lab[m.group(1)] < i:
             seg = b[lab[m.group(1)]:i + 1]
             nmed = sum("v_med3" in x for x in seg)
-            if nmed >= 20 and len(seg) < 1500 and (best is None or nmed > best[0]):
+            nval = sum(x.startswith("\tv_") for x in seg)
+            # the sweep loop proper: many rows, fewest VALU instructions per row (enclosing loops carry other phases)
+            if nmed >= 40 and (best is None or nval / nmed < best[1] / best[0]):
                 best = (nmed, sum(x.startswith("\tv_") for x in seg), sum(x.startswith("\ts_") for x in seg),
                         sum("v_readlane" in x for x in seg), sum("v_writelane" in x for x in seg), sum("scratch_" in x for x in seg),
                         sum("s_waitcnt" in x or "s_nop" in x for x in seg))
-    print("<%s>" % ",".join(name), "largest sweep loop: med3 %d  VALU %d (%.2f per row)  SALU %d  readlane %d  writelane %d  scratch %d  waitcnt/nop %d"
+    print("<%s>" % ",".join(name), "sweep loop: med3 %d  VALU %d (%.2f per row)  SALU %d  readlane %d  writelane %d  scratch %d  waitcnt/nop %d"
           % (best[0], best[1], best[1] / best[0], best[2], best[3], best[4], best[5], best[6]) if best else "no loop found")
