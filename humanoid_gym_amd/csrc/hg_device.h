@@ -1,7 +1,7 @@
 // hg_device.h -- device-side data layout of libhg_sim (gfx950 only).
 //
 // One wavefront (64 lanes) simulates one env.  The robot description is a
-// single read-only DevModel in HBM (about 30 KB, L2 resident); per-env state
+// single read-only DevModel in HBM (27 KB, L2 resident); per-env state
 // is an env-major float record (include/hg_model.h, HG_STATE_SIZE; padded in the library's own
 // buffer to a whole number of 64-byte lines) so that the 64 lanes of the env's wave read and write
 // it as one contiguous, line-aligned burst.

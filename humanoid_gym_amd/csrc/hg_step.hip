@@ -24,7 +24,9 @@
 //     impulses live in scalar registers) and every lane j updates its candidate
 //     with A[j][i].  This is the impulse-space form of Bullet's velocity-space
 //     sweep (w = J dv), same iterates, no reductions; violated joint limits ride
-//     along as extra rows on the wave's spare lanes;
+//     along as extra rows on the wave's spare lanes.  Models with more than 64 rows (NAO / Romeo with
+//     their finger joints) carry two rows per lane -- motor row and contact row -- with the impulses in
+//     two VGPRs and the CHANGE of an impulse broadcast instead (see "row layout" in phase 4);
 //   * the final M^-1 J^T lambda is one more level-by-level ABA response.
 // Scheduling: one wave per workgroup (a workgroup of several envs keeps its LDS until its slowest wave ends:
 // measured slower); launches that fit the GPU at once reverse the SIMD arbiter's service order of their
