@@ -20,6 +20,8 @@ constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
 constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
 constexpr int CON   = 12;   // floats per contact record
+// the cache record of a link once it has been turned to world-aligned axes (hg_step.hip, 3b)
+constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10;
 
 // DevModel::link[i][...]
 enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTIA = 22,
@@ -89,7 +91,7 @@ struct StepOut {
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
 // vel/F and lam/misc share storage (never live together); region AB is time-shared, see hg_step.hip.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, AB, acc, total;
+    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, rq, AB, acc, total;
 };
 // With self-collision two more arrays exist, never live together, so they share one region: the world centres
 // (+ radius) of the n_self spheres that appear in pairs (contact detection), and the second-path Y values of
@@ -108,7 +110,9 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.con = o;   o += CON * (nc3 / 3);
     p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
     p.sdist = o; o += rup4(ns);
-    p.tab = o;   o += rup4(4 * n);          // int tables: next_sibling, base_children, first_child, lev_order
+    p.tab = o;   o += rup4(n);              // byte tables (4 n bytes): next_sibling, base_children, first_child, lev_order
+    p.rq = o;    o += 4 * n;                // world orientation of every link as a quaternion, from the kinematics to the
+                                            // conversion of the ABA cache to world-aligned axes (hg_step.hip, 3b)
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);
     p.total = o;

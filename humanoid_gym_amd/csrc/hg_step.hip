@@ -145,10 +145,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     float *const sdistL = lds + L.sdist;
     float *const scenL = lds + L.scen;       // centres + radius of the spheres that appear in pairs (detection), with self-collision
     float *const Yd2L = lds + L.Yd2;         // second path of two-body rows, [maxlev][NC3] (phase 4a); shares scen's storage
-    int *const nsibL = reinterpret_cast<int *>(lds + L.tab);        // next_sibling[n]
-    int *const bchL = nsibL + n;                                    // base_children[n]
-    int *const fchL = nsibL + 2 * n;                                // first_child[n]
-    int *const ordL = nsibL + 3 * n;                                // links sorted by level
+    signed char *const nsibL = reinterpret_cast<signed char *>(lds + L.tab);     // next_sibling[n]   (bytes: indices are < 64)
+    signed char *const bchL = nsibL + n;                                         // base_children[n]
+    signed char *const fchL = nsibL + 2 * n;                                     // first_child[n]
+    signed char *const ordL = nsibL + 3 * n;                                     // links sorted by level
+    float *const rqL = lds + L.rq;                                               // world orientation quaternion of every link
     // region AB is time-shared: kinematics exchange (pub) -> child-to-parent ABA exchange (up)
     // -> contact Jacobians (Jc) -> 6-float exchanges of the final response
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
@@ -171,9 +172,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const unsigned kids_w = is_link ? M->kids[li] : 0u;
     const int nbc = P.n_base_children;
     if (is_link) {
-        nsibL[lane] = (int)((kids_w >> 8) & 0xffu) - 1;
-        bchL[lane] = lane < nbc ? M->base_children[lane] : -1;
-        fchL[lane] = (int)(kids_w & 0xffu) - 1;
+        nsibL[lane] = (signed char)((int)((kids_w >> 8) & 0xffu) - 1);
+        bchL[lane] = lane < nbc ? M->base_children[lane] : (signed char)-1;
+        fchL[lane] = (signed char)((int)(kids_w & 0xffu) - 1);
         ordL[lane] = M->lev_order[lane];
     }
 
@@ -280,11 +281,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         HG_TICK(2);
         Sv v = v0;
         V3 gl = v3(0, 0, 0);                   // gravity in the link frame
+        M3 Rw;                                 // world orientation of this lane's link
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.f : 0.f;
         #pragma unroll 1
         for (int lev = 1; lev <= maxlev; ++lev) {
             if (is_link && mylev == lev) {
                 const float *pp = pubL + PUB * pidx;
-                const M3 Rw = mul_bt(ldm(pp), E);
+                Rw = mul_bt(ldm(pp), E);
                 const V3 xw = ld3(pp + 9) + mulv(Rw, r);
                 v = sfma(Sm, qd, xmotion(E, r, ldsv(pp + 12)));
                 float *po = pubL + PUB * lane;
@@ -296,6 +300,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
             }
             wave_sync();
+        }
+        if (is_link) {       // kept (4 floats) until the ABA cache is turned to world-aligned axes in 3b
+            float qq[4];
+            mat_to_quat(Rw, qq);
+            *reinterpret_cast<float4 *>(rqL + 4 * lane) = make_float4(qq[0], qq[1], qq[2], qq[3]);
         }
 
         HG_TICK(3);
@@ -556,6 +565,26 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 wave_sync();
             }
         }
+        // ============ 3b. the ABA cache in world-aligned axes ===================================
+        // From here on (impulse responses of the rows, final response) every link's quantities are used in axes
+        // parallel to the world's with the origin at the link's own COM: the transform between a link and its parent
+        // is then a pure translation by r_w (6 VALU where the joint transform E costs 24, 16 floats per link
+        // from LDS instead of 25), and origins stay where they were, so nothing cancels that did not cancel before.
+        // Record: [0:3) r_w parent COM -> link COM, [3] 1/D, [4:10) U_w, [10:16) S_w; [26], [27] motor limits as before.
+        if (is_link) {
+            float *pc = cacheL + CACHE * lane;
+            const float4 qv = *reinterpret_cast<const float4 *>(rqL + 4 * lane);
+            const M3 Rl = quat_to_mat(qv.x, qv.y, qv.z, qv.w);
+            const V3 rl = ld3(pc + 9);
+            const Sv Ul = ldsv(pc + 12), Sl = ldsv(pc + 20);
+            const float Dinv = pc[18];
+            Sv Uw, Sw;
+            Uw.a = mulv(Rl, Ul.a); Uw.l = mulv(Rl, Ul.l);
+            Sw.a = mulv(Rl, Sl.a); Sw.l = mulv(Rl, Sl.l);
+            st3(pc + C_RW, mulv(Rl, rl)); pc[C_DINV] = Dinv;
+            stsv(pc + C_UW, Uw); stsv(pc + C_SW, Sw);
+        }
+        wave_sync();
         HG_TICK(6);
         // velocities += dt * unconstrained acceleration
         // (every velocity coordinate is clamped to +-vmax after each update, as btMultiBody does)
@@ -788,10 +817,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     if (l >= 0) {
                         const float *pc = cacheL + CACHE * l;
                         const float f = unit_row ? (l == body ? R.unit_f : 0.f) : JcL[(6 + l) * NC3 + col];
-                        const Sv Sl = ldsv(pc + 20);
-                        const Sv Ul = ldsv(pc + 12);
+                        const Sv Sl = ldsv(pc + C_SW);
+                        const Sv Ul = ldsv(pc + C_UW);
                         Y = f - sdot(Sl, Z);
-                        Z = xforce_up(ldm(pc), ld3(pc + 9), sfma(Ul, Y * pc[18], Z));
+                        Z = sfma(Ul, Y * pc[C_DINV], Z);
+                        Z.a = Z.a + cross(ld3(pc + C_RW), Z.l);        // to the parent's origin
                     }
                 }
                 Ys[dd - 1] = Y;
@@ -810,8 +840,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                             const float *pc = cacheL + CACHE * l;
                             // entries of links shared with the first branch are zero in Jc (they cancel)
                             const float f = ((R.myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];
-                            Y = f - sdot(ldsv(pc + 20), Z2);
-                            Z2 = xforce_up(ldm(pc), ld3(pc + 9), sfma(ldsv(pc + 12), Y * pc[18], Z2));
+                            Y = f - sdot(ldsv(pc + C_SW), Z2);
+                            Z2 = sfma(ldsv(pc + C_UW), Y * pc[C_DINV], Z2);
+                            Z2.a = Z2.a + cross(ld3(pc + C_RW), Z2.l);
                         }
                         if (col >= 0) Yd2L[(dd - 1) * NC3 + col] = Y;
                     }
@@ -819,11 +850,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 Z = Z + Z2;
             }
             // (ii) base
+            // (Z arrives in world axes at the base COM; the base's inverse inertia is kept in its body frame)
             const M3 Rb = ldm(baseL);
-            Z.a = Z.a - tmulv(Rb, R.Jang);
-            Z.l = Z.l - tmulv(Rb, R.Jlin);
-            const Sv ab = neg_mul6(baseL + 12, Z);       // IA0^-1 streamed from LDS
-            const V3 uba = mulv(Rb, ab.a), ubl = mulv(Rb, ab.l);
+            Z.a = tmulv(Rb, Z.a - R.Jang);
+            Z.l = tmulv(Rb, Z.l - R.Jlin);
+            const Sv abb = neg_mul6(baseL + 12, Z);      // IA0^-1 streamed from LDS
+            const V3 uba = mulv(Rb, abb.a), ubl = mulv(Rb, abb.l);
+            Sv ab; ab.a = uba; ab.l = ubl;               // world axes
             xdiag = dot(uba, R.Jang) + dot(ubl, R.Jlin);
             if (nc > 0) {
                 const float ub[6] = {uba.x, uba.y, uba.z, ubl.x, ubl.y, ubl.z};
@@ -844,14 +877,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 // parent acceleration: previous link, base, or a saved branching link -- a scalar branch
                 // per case (mode is wave-uniform), so no register copies are needed to pick one
                 Sv a;
-                if (mode == 0) a = xmotion(ldm(pc), ld3(pc + 9), acur);
-                else if (mode == 1) a = xmotion(ldm(pc), ld3(pc + 9), ab);
+                if (mode == 0) a = acur;
+                else if (mode == 1) a = ab;
                 else {
-                    Sv ap = ab;
+                    a = ab;
 #pragma unroll
-                    for (int s = 0; s < NSL; s++) if (mode == 2 + s) ap = slot[s];
-                    a = xmotion(ldm(pc), ld3(pc + 9), ap);
+                    for (int s = 0; s < NSL; s++) if (mode == 2 + s) a = slot[s];
                 }
+                a.l = a.l + cross(a.a, ld3(pc + C_RW));        // the same acceleration at this link's origin
                 // Y of this link: non-zero only if it is the own-path link of its depth d (wave-uniform)
                 const int d = (int)((inf >> 8) & 0xffu);
                 bool on_path;              // bit i of the ancestor mask, as 32-bit operations (i is wave-uniform)
@@ -865,8 +898,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     else on2 = (((i < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (i & 31)) & 1u) != 0u;
                     if (on2) Y += Yd2L[(d - 1) * NC3 + col];
                 }
-                const float qa = (Y - sdot(ldsv(pc + 12), a)) * pc[18];
-                a = sfma(ldsv(pc + 20), qa, a);
+                const float qa = (Y - sdot(ldsv(pc + C_UW), a)) * pc[C_DINV];
+                a = sfma(ldsv(pc + C_SW), qa, a);
                 acur = a;
                 const int sv = (int)((inf >> 16) & 0xffu) - 1;
                 if (sv >= 0) {
@@ -1252,11 +1285,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const float Fi = is_link ? FL[6 + lane] : 0.f;
             float Y = 0.f;
             const float *pcm = cacheL + CACHE * li;
-            const M3 E = ldm(pcm);
-            const V3 r = ld3(pcm + 9);
-            const Sv U = ldsv(pcm + 12);
-            const float Dinv = pcm[18];
-            const Sv Sm = ldsv(pcm + 20);
+            const V3 rw = ld3(pcm + C_RW);
+            const Sv U = ldsv(pcm + C_UW);
+            const float Dinv = pcm[C_DINV];
+            const Sv Sm = ldsv(pcm + C_SW);
             const M3 Rw0 = ldm(baseL);
             #pragma unroll 1
             for (int lev = maxlev; lev >= 1; --lev) {
@@ -1265,23 +1297,27 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     #pragma unroll 1
                     for (int c = first_child; c >= 0; c = nsibL[c]) Z = Z + ldsv(up6 + 8 * c);
                     Y = Fi - sdot(Sm, Z);
-                    stsv(up6 + 8 * lane, xforce_up(E, r, sfma(U, Y * Dinv, Z)));
+                    Z = sfma(U, Y * Dinv, Z);
+                    Z.a = Z.a + cross(rw, Z.l);
+                    stsv(up6 + 8 * lane, Z);
                 }
                 wave_sync();
             }
             Sv Z0; Z0.a = v3(0, 0, 0); Z0.l = v3(0, 0, 0);
             #pragma unroll 1
             for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * bchL[k]);
-            Z0.a = Z0.a - tmulv(Rw0, ld3(FL));
-            Z0.l = Z0.l - tmulv(Rw0, ld3(FL + 3));
-            const Sv ab = neg_mul6(baseL + 12, Z0);
+            Z0.a = tmulv(Rw0, Z0.a - ld3(FL));
+            Z0.l = tmulv(Rw0, Z0.l - ld3(FL + 3));
+            const Sv abb = neg_mul6(baseL + 12, Z0);
+            Sv ab; ab.a = mulv(Rw0, abb.a); ab.l = mulv(Rw0, abb.l);      // world axes
             if (lane == 0) stsv(pub6 + 8 * n, ab);
             wave_sync();
             float dq = 0.f;
             #pragma unroll 1
             for (int lev = 1; lev <= maxlev; ++lev) {
                 if (is_link && mylev == lev) {
-                    Sv a = xmotion(E, r, ldsv(pub6 + 8 * pidx));
+                    Sv a = ldsv(pub6 + 8 * pidx);
+                    a.l = a.l + cross(a.a, rw);
                     dq = (Y - sdot(U, a)) * Dinv;
                     a = sfma(Sm, dq, a);
                     stsv(pub6 + 8 * lane, a);
@@ -1289,8 +1325,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 wave_sync();
             }
             qd = clampv((is_link ? accL[lane] : 0.f) + dq, P.vmax);   // qd was parked in LDS, q is re-read from the record
-            bang = clamp3(bang + mulv(Rw0, ab.a), P.vmax);
-            bvel = clamp3(bvel + mulv(Rw0, ab.l), P.vmax);
+            bang = clamp3(bang + ab.a, P.vmax);
+            bvel = clamp3(bvel + ab.l, P.vmax);
         }
 
         HG_TICK(10);
