@@ -91,28 +91,38 @@ struct StepOut {
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
 // vel/F and lam/misc share storage (never live together); region AB is time-shared, see hg_step.hip.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, rq, AB, acc, total;
+    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, rq, ys, AB, acc, total;
 };
 // With self-collision two more arrays exist, never live together, so they share one region: the world centres
 // (+ radius) of the n_self spheres that appear in pairs (contact detection), and the second-path Y values of
 // two-body rows, kept for the contact-row lanes only (maxlev x nc3, phase 4a).
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows) {
+// Variants whose impulse-response pass keeps the own-path `Y` values (one per depth and lane) in LDS instead of
+// registers: DEPTH * WAVE floats laid over three arrays that are dead by then (joint axes / pivots, sphere
+// distances, link orientations).  For the shapes where hipcc would otherwise spill them to scratch.
+#ifndef HG_YS_LDS
+#define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 && (nmx) + 3 * (maxc) <= 64)
+#endif
+__host__ __device__ constexpr int ys_floats(int nmx, int maxc, int depth) { return HG_YS_LDS(nmx, maxc, depth) ? depth * WAVE : 0; }
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows, int ys) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
     p.cache = o; o += CACHE * n;
-    p.jw = o;    o += 8 * n;
     p.base = o;  o += 64;
     p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
     p.lam = o;   p.misc = o; o += nrows > WAVE ? WAVE + rup4(nc3) : WAVE;      // impulses of all rows (two rows per lane beyond 64)
     p.con = o;   o += CON * (nc3 / 3);
     p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
-    p.sdist = o; o += rup4(ns);
     p.tab = o;   o += rup4(n);              // byte tables (4 n bytes): next_sibling, base_children, first_child, lev_order
+    // three arrays that are dead once the rows are set up, and the Y values of the response pass laid over them
+    p.ys = o;
+    p.jw = o;    o += 8 * n;                // world joint axes / pivots (kinematics -> contact Jacobians)
+    p.sdist = o; o += rup4(ns);             // sphere - plane distances (contact detection)
     p.rq = o;    o += 4 * n;                // world orientation of every link as a quaternion, from the kinematics to the
                                             // conversion of the ABA cache to world-aligned axes (hg_step.hip, 3b)
+    o = imax(o, p.ys + ys);
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);
     p.total = o;

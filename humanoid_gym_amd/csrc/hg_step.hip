@@ -82,7 +82,7 @@ HG_FI void wave_sync() {
 
 // Y = Ys[d - 1] if link i (depth d) lies on the row's own path -- bit i of its ancestor mask, so the packed path
 // words are dead once the walk is done -- else 0; one case per depth so that Ys is indexed by compile-time constants only.
-#define HG_Y_CASE(K) case K + 1: if constexpr (K < DEPTH) { Y = on_path ? Ys[K < DEPTH ? K : 0] : 0.f; } break;
+#define HG_Y_CASE(K) case K + 1: if constexpr (K < DEPTH) { Y = on_path ? Ys[K < YSN ? K : 0] : 0.f; } break;
 #define HG_Y_CASES HG_Y_CASE(0) HG_Y_CASE(1) HG_Y_CASE(2) HG_Y_CASE(3) HG_Y_CASE(4) HG_Y_CASE(5) \
                    HG_Y_CASE(6) HG_Y_CASE(7) HG_Y_CASE(8) HG_Y_CASE(9) HG_Y_CASE(10) HG_Y_CASE(11)
 
@@ -128,7 +128,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ndof = 6 + n;
     const int ns = P.n_spheres;
     const int maxlev = P.maxlev;
-    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self, NROWS);
+    constexpr bool YSL = ys_floats(NMX, MAXC, DEPTH) > 0;      // own-path Y values of the response pass in LDS (hg_device.h)
+    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self, NROWS, ys_floats(NMX, MAXC, DEPTH));
     // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
     // leave them in VGPRs that stay live for the whole kernel)
     L.AB = __builtin_amdgcn_readfirstlane(L.AB);
@@ -149,6 +150,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     signed char *const bchL = nsibL + n;                                         // base_children[n]
     signed char *const fchL = nsibL + 2 * n;                                     // first_child[n]
     signed char *const ordL = nsibL + 3 * n;                                     // links sorted by level
+    float *const ysL = lds + L.ys;
     float *const rqL = lds + L.rq;                                               // world orientation quaternion of every link
     // region AB is time-shared: kinematics exchange (pub) -> child-to-parent ABA exchange (up)
     // -> contact Jacobians (Jc) -> 6-float exchanges of the final response
@@ -732,17 +734,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // Joint-limit rows (btMultiBodyJointLimitConstraint): one per violated bound, Jacobian +-1 on the joint
         // (so its impulse response is +- the motor row's: the row shares the motor's lane), desired
         // velocity 0 with the Baumgarte term -penetration * erp / dt, impulse in [0, limhi].
-        float lim_s = 0.f, lim_b = 0.f;
-        if (R0.motor && (P.flags & F_LIMITS)) {
-            const float *lkl = M->link[lane];
-            if (lkl[L_LIMITED] != 0.f) {
-                const float pen_lo = q - lkl[L_LOWER], pen_hi = lkl[L_UPPER] - q;
-                float pen = 0.f;
-                if (pen_lo <= 0.f) { lim_s = 1.f; pen = pen_lo; }
-                else if (pen_hi <= 0.f) { lim_s = -1.f; pen = pen_hi; }
-                lim_b = -pen * P.erp * P.inv_dt - lim_s * qd;
+        // (evaluated twice, before and after the impulse-response pass, from q of the state record and the parked qd:
+        // two values fewer to keep alive across that pass, where the A-row leaves no register to spare)
+        auto limit_row = [&](int ln, float ql, float qdl, float &ls, float &lb) __attribute__((always_inline)) {
+            ls = 0.f; lb = 0.f;
+            if (ln < n && (P.flags & F_LIMITS)) {
+                const float *lkl = M->link[ln];
+                if (lkl[L_LIMITED] != 0.f) {
+                    const float pen_lo = ql - lkl[L_LOWER], pen_hi = lkl[L_UPPER] - ql;
+                    float pen = 0.f;
+                    if (pen_lo <= 0.f) { ls = 1.f; pen = pen_lo; }
+                    else if (pen_hi <= 0.f) { ls = -1.f; pen = pen_hi; }
+                    lb = -pen * P.erp * P.inv_dt - ls * qdl;
+                }
             }
-        }
+        };
+        float lim_s, lim_b;
+        limit_row(lane, q, qd, lim_s, lim_b);
         const unsigned long long limmask = __ballot(lim_s != 0.f);       // wave-uniform
         // Limit rows on spare lanes (one row per lane only).  The wave has 64 - NROWS lanes without a row; up to KL of
         // them take one violated joint limit each and become ordinary rows: lane NROWS + k (slot k) carries a row with
@@ -779,6 +787,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             R0.pw[0] = t.x; R0.pw[1] = t.y; R0.pw[2] = t.z;
         }
         RC.two_body = __ballot(RC.myanc2 != 0ull) != 0ull;   // wave-uniform
+        lamL[lane] = R0.target_err;       // parked across the impulse-response pass (the impulses' own storage, unused until the sweeps end)
         wave_sync();
 
         HG_TICK(7);
@@ -808,7 +817,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const unsigned pw[3] = {R.pw[0], R.pw[1], R.pw[2]};
             // (i) walk the own path towards the root, accumulating the zero-acceleration force
             Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
-            float Ys[DEPTH];             // Y of the own-path link at each depth (registers)
+            constexpr int YSN = YSL ? 1 : DEPTH;
+            float Ys[YSN];               // Y of the own-path link at each depth (registers; LDS for the YSL variants)
 #pragma unroll
             for (int dd = DEPTH; dd >= 1; --dd) {
                 float Y = 0.f;
@@ -824,7 +834,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         Z.a = Z.a + cross(ld3(pc + C_RW), Z.l);        // to the parent's origin
                     }
                 }
-                Ys[dd - 1] = Y;
+                if constexpr (YSL) ysL[(dd - 1) * WAVE + lane] = Y; else Ys[dd - 1] = Y;
             }
             if (R.two_body) {
                 // The impulse of a self-contact row acts on two branches.  By linearity the second
@@ -891,7 +901,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if constexpr (NMX <= 32) on_path = (((unsigned)R.myanc >> i) & 1u) != 0u;
                 else on_path = (((i < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (i & 31)) & 1u) != 0u;
                 float Y = 0.f;
-                switch (d) { HG_Y_CASES default: break; }
+                if constexpr (YSL) { const float y = ysL[(d - 1) * WAVE + lane]; Y = on_path ? y : 0.f; }      // own lane's value: no sync
+                else { switch (d) { HG_Y_CASES default: break; } }
                 if (R.two_body) {          // myanc2 != 0 only on contact-row lanes
                     bool on2;
                     if constexpr (NMX <= 32) on2 = (((unsigned)R.myanc2 >> i) & 1u) != 0u;
@@ -925,7 +936,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         const bool row_motor = R0.motor, row_slot = R0.slot;
         const bool row_contact = DUAL ? false : R0.contact;      // set-0 view (one row per lane): the solver below
         const int col = DUAL ? -1 : R0.col;
-        const float target_err = R0.target_err;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));          // fresh address arithmetic
+        const float target_err = lamL[lane_e];
+        {   // same values as before the pass
+            const bool lk_e = lane_e < n;
+            limit_row(lane_e, lk_e ? st[HG_STATE_BASE + lane_e] : 0.f, lk_e ? accL[lane_e] : 0.f, lim_s, lim_b);
+        }
         const bool row_active = row_motor || row_contact || row_slot;
 
         HG_TICK(8);
@@ -1284,7 +1301,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const int first_child = is_link ? fchL[lane] : -1;
             const float Fi = is_link ? FL[6 + lane] : 0.f;
             float Y = 0.f;
-            const float *pcm = cacheL + CACHE * li;
+            int lane_f = lane;
+            asm volatile("" : "+v"(lane_f));      // fresh: the substep's `li` would stay live (spilled) across the solver
+            const float *pcm = cacheL + CACHE * (lane_f < n ? lane_f : 0);
             const V3 rw = ld3(pcm + C_RW);
             const Sv U = ldsv(pcm + C_UW);
             const float Dinv = pcm[C_DINV];
