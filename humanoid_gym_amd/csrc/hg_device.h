@@ -100,9 +100,11 @@ __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 // Variants whose impulse-response pass keeps the own-path `Y` values (one per depth and lane) in LDS instead of
 // registers: DEPTH * WAVE floats laid over three arrays that are dead by then (joint axes / pivots, sphere
-// distances, link orientations).  For the shapes where hipcc would otherwise spill them to scratch.
+// distances, link orientations).  For the shapes whose A-rows leave no registers for them: 12 contact slots (hipcc
+// spilled them to scratch) and two rows per lane (NAO + fingers 6 % faster, Romeo + hands 4.5 %).  Measured on the
+// others too: NAO and Pepper within 1 %, Romeo 10 % slower (the extra 1.3 KB of LDS costs it a wave per SIMD).
 #ifndef HG_YS_LDS
-#define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 && (nmx) + 3 * (maxc) <= 64)
+#define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 || (nmx) + 3 * (maxc) > 64)
 #endif
 __host__ __device__ constexpr int ys_floats(int nmx, int maxc, int depth) { return HG_YS_LDS(nmx, maxc, depth) ? depth * WAVE : 0; }
 __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows, int ys) {
