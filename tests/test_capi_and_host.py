@@ -172,3 +172,24 @@ def test_box_space_fallback():
     b = spaces.Box(np.array([-1.0, 0.0], dtype=np.float32), np.array([1.0, 2.0], dtype=np.float32))
     for _ in range(10):
         assert b.contains(b.sample())
+
+
+def test_reference_robot_kernel_variants_use_no_scratch():
+    """build() records hipcc's resource remarks per instantiation of the step kernel (csrc/kernel_resources.json).
+    The variants that the reference's four robots run on keep everything in registers and LDS:
+    no scratch, and the occupancy the LDS plan is sized for."""
+    import json
+    from humanoid_gym_amd import build as hb
+    from humanoid_gym_amd.robots import load_robot
+    if not os.path.exists(hb.RESOURCES) or hb.needs_build():
+        pytest.skip("kernel_resources.json is written by humanoid_gym_amd.build.build(); library not built from these sources")
+    res = json.load(open(hb.RESOURCES))
+    expect = {"dancer": ("<18,12,6,0,4>", 4), "nao": ("<26,8,6,0,4>", 4), "pepper": ("<20,8,9,2,4>", 4),
+              "romeo": ("<37,8,12,2,3>", 3), "nao_hands": ("<44,8,12,2,2>", 2)}
+    for robot, (variant, waves) in expect.items():
+        model, cfg = load_robot(robot)
+        nmx, maxc = (int(x) for x in variant.strip("<>").split(",")[:2])
+        assert model.n_links <= nmx and cfg.max_contacts <= maxc, robot          # the shape fits the variant named here
+        r = res[variant]
+        assert r["scratch_bytes_per_lane"] == 0, (robot, variant, r)
+        assert r["occupancy_waves_per_simd"] == waves, (robot, variant, r)
