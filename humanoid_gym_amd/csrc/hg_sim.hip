@@ -265,7 +265,7 @@ namespace hg {
 // kernel instantiations: motor lanes, contact slots, tree depth, branch slots, waves per SIMD
 struct Variant { int nmx, maxc, depth, nsl, wpe; };
 #define HG_VARIANTS(X) \
-    X(0, 18, 12, 6, 0, 4)  /* dancer (3 waves/SIMD would need no scratch but is 18 % slower) */ \
+    X(0, 18, 12, 6, 0, 4)  /* dancer (scratch-free at 4 waves/SIMD since round 2; 3 waves/SIMD is 18 % slower) */ \
     X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
     X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
     X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \

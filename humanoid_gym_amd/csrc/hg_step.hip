@@ -284,26 +284,28 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         Sv v = v0;
         V3 gl = v3(0, 0, 0);                   // gravity in the link frame
         M3 Rw;                                 // world orientation of this lane's link
+        V3 xw = v3(0, 0, 0);                   // its COM
 #pragma unroll
         for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.f : 0.f;
         #pragma unroll 1
-        for (int lev = 1; lev <= maxlev; ++lev) {
+        for (int lev = 1; lev <= maxlev; ++lev) {      // the body is issued maxlev times: only what the children wait for
             if (is_link && mylev == lev) {
                 const float *pp = pubL + PUB * pidx;
                 Rw = mul_bt(ldm(pp), E);
-                const V3 xw = ld3(pp + 9) + mulv(Rw, r);
+                xw = ld3(pp + 9) + mulv(Rw, r);
                 v = sfma(Sm, qd, xmotion(E, r, ldsv(pp + 12)));
                 float *po = pubL + PUB * lane;
                 stm(po, Rw); st3(po + 9, xw); stsv(po + 12, v);
-                gl = tmulv(Rw, v3(P.gx, P.gy, P.gz));
-                // world-frame joint axis and pivot for the contact Jacobians
-                float *pj = jwL + 8 * lane;
-                st3(pj, mulv(Rw, ax));
-                st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
             }
             wave_sync();
         }
-        if (is_link) {       // kept (4 floats) until the ABA cache is turned to world-aligned axes in 3b
+        if (is_link) {       // once per link, after the sweep
+            gl = tmulv(Rw, v3(P.gx, P.gy, P.gz));
+            // world-frame joint axis and pivot for the contact Jacobians
+            float *pj = jwL + 8 * lane;
+            st3(pj, mulv(Rw, ax));
+            st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
+            // world orientation, kept (4 floats) until the ABA cache is turned to world-aligned axes in 3b
             float qq[4];
             mat_to_quat(Rw, qq);
             *reinterpret_cast<float4 *>(rqL + 4 * lane) = make_float4(qq[0], qq[1], qq[2], qq[3]);
@@ -533,14 +535,22 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int j = 0; j < 3; j++) A6[6 * (3 + j) + i] = A6[6 * i + 3 + j];
             A6[27] = A6[22]; A6[33] = A6[23]; A6[34] = A6[29];
-            float Inv[36];
-            spd6_inverse(A6, Inv);
-            a0 = neg_mul6(Inv, p0);
-            if (lane == 0) {
+            // One factorisation (replicated), then every lane solves ONE system: lanes 0-5 the unit vectors -- row `lane` of
+            // the inverse, which the impulse responses stream from LDS -- and the other lanes -p0, the base acceleration.
+            float Lc[36], rd[6], rhs[6], x[6];
+            spd6_cholesky(A6, Lc, rd);
+            const float p6[6] = {p0.a.x, p0.a.y, p0.a.z, p0.l.x, p0.l.y, p0.l.z};
 #pragma unroll
-                for (int k = 0; k < 36; k++) baseL[12 + k] = Inv[k];
-                stsv(accL + 8 * n, a0);
+            for (int k = 0; k < 6; k++) rhs[k] = lane < 6 ? (lane == k ? 1.f : 0.f) : -p6[k];
+            chol6_solve(Lc, rd, rhs, x);
+            if (lane < 6) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) baseL[12 + 6 * lane + k] = x[k];
             }
+#pragma unroll
+            for (int k = 0; k < 6; k++) x[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[k]), 6));      // lane 6 solved for -p0
+            a0.a = v3(x[0], x[1], x[2]); a0.l = v3(x[3], x[4], x[5]);
+            if (lane == 0) stsv(accL + 8 * n, a0);
         }
         wave_sync();
         // root -> leaves: accelerations
