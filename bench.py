@@ -103,6 +103,14 @@ def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
     c0 = time.perf_counter()
     for t in range(1000):
         one.step(acts[t])
+    # flops of the same workload as the oracle's instrumented build counts them, beside the formula that
+    # `valu` is priced with; one env, the second pass over the trajectory (standing on both feet)
+    from _oracle import counted_flops_per_env_step
+    cnt = counted_flops_per_env_step(model, cfg, np.concatenate([rows, rows]), sel, warmup=T_TRAJ)
+    out["counted_flops_per_env_step"] = {"value": cnt["flops_per_env_step"], "mean_contacts": cnt["mean_contacts"],
+                                         "formula": algorithmic_flops_per_env_step(model, cfg, n_contacts=round(cnt["mean_contacts"])),
+                                         "note": "oracle/libhg_oracle_flops.so (-DHGO_COUNT_FLOPS): multiplies + adds the FP64 "
+                                                 "restatement executes per env step; `valu` uses the formula"}
     out["single_thread"] = {"value": 1000 / (time.perf_counter() - c0), "unit": "env-steps/s",
                             "sample": "BASELINE configs[0]: nao, 1 env x 1000 random_control steps, oracle FP64, "
                                       "includes the ctypes call per step"}

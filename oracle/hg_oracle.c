@@ -46,6 +46,19 @@
 
 #include "../include/hg_model.h"
 
+/* Flop counting ("replace the estimated constants with counted values from the oracle's
+ * instrumented build").  With -DHGO_COUNT_FLOPS (make libhg_oracle_flops.so) every arithmetic block adds the
+ * multiplies + adds / subtracts it executes (a divide, sqrt, sin or cos counts 1) to a thread-local counter;
+ * hgo_flops_reset / hgo_flops_read expose it.  This counts what THIS formulation executes (dense 6x6 products in
+ * the ABA included), so it is an upper estimate of the algorithmic work, not of what the kernel issues.
+ * The normal build compiles the macro away. */
+#ifdef HGO_COUNT_FLOPS
+static _Thread_local double hgo_flop_counter;
+#define HGO_FLOPS(k) (hgo_flop_counter += (double)(k))
+#else
+#define HGO_FLOPS(k) ((void)0)
+#endif
+
 #define NL HG_MAX_LINKS
 #define NDOF_MAX (6 + HG_MAX_LINKS)
 #define NROWS_MAX (2 * HG_MAX_LINKS + 3 * HG_MAX_CONTACTS)
@@ -54,17 +67,20 @@
 /* small linear algebra                                                */
 /* ------------------------------------------------------------------ */
 static void v3_cross(const double a[3], const double b[3], double o[3]) {
+    HGO_FLOPS(9);
     double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
     o[0] = x; o[1] = y; o[2] = z;
 }
-static double v3_dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3_dot(const double a[3], const double b[3]) { HGO_FLOPS(5); return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 static void m3_mulv(const double M[9], const double v[3], double o[3]) {
+    HGO_FLOPS(15);
     double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
     double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
     double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
     o[0] = x; o[1] = y; o[2] = z;
 }
 static void m3_tmulv(const double M[9], const double v[3], double o[3]) { /* M^T v */
+    HGO_FLOPS(15);
     double x = M[0] * v[0] + M[3] * v[1] + M[6] * v[2];
     double y = M[1] * v[0] + M[4] * v[1] + M[7] * v[2];
     double z = M[2] * v[0] + M[5] * v[1] + M[8] * v[2];
@@ -72,6 +88,7 @@ static void m3_tmulv(const double M[9], const double v[3], double o[3]) { /* M^T
 }
 static void m3_mul(const double A[9], const double B[9], double O[9]) {
     double T[9];
+    HGO_FLOPS(45);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
@@ -79,6 +96,7 @@ static void m3_mul(const double A[9], const double B[9], double O[9]) {
 }
 static void m3_mul_bt(const double A[9], const double B[9], double O[9]) { /* A B^T */
     double T[9];
+    HGO_FLOPS(45);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             T[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
@@ -86,6 +104,7 @@ static void m3_mul_bt(const double A[9], const double B[9], double O[9]) { /* A 
 }
 static void quat_to_mat(const double q[4], double R[9]) { /* xyzw, body->world */
     double x = q[0], y = q[1], z = q[2], w = q[3];
+    HGO_FLOPS(30);
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
     R[3] = 2 * (x * y + z * w);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
     R[6] = 2 * (x * z - y * w);     R[7] = 2 * (y * z + x * w);     R[8] = 1 - 2 * (x * x + y * y);
@@ -101,6 +120,7 @@ static void mat_to_quat(const double m[9], double q[4]) {
 /* rotation about unit axis a by angle th (active, right-handed) */
 static void axis_angle(const double a[3], double th, double R[9]) {
     double c = cos(th), s = sin(th), t = 1 - c;
+    HGO_FLOPS(3 + 27);
     R[0] = t * a[0] * a[0] + c;        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
     R[3] = t * a[0] * a[1] + s * a[2]; R[4] = t * a[1] * a[1] + c;        R[5] = t * a[1] * a[2] - s * a[0];
     R[6] = t * a[0] * a[2] - s * a[1]; R[7] = t * a[1] * a[2] + s * a[0]; R[8] = t * a[2] * a[2] + c;
@@ -127,6 +147,7 @@ typedef struct {
 static void motion_xform(const double E[9], const double r[3], const double vp[6], double vc[6]) {
     /* child <- parent:  w' = E w ; v' = E v + w' x r */
     double w[3], v[3], c[3];
+    HGO_FLOPS(3);
     m3_mulv(E, vp, w);
     m3_mulv(E, vp + 3, v);
     v3_cross(w, r, c);
@@ -136,6 +157,7 @@ static void motion_xform(const double E[9], const double r[3], const double vp[6
 static void force_xform_to_parent(const double E[9], const double r[3], const double fc[6], double fp[6]) {
     /* parent <- child:  f = E^T f_c ; n = E^T (n_c + r x f_c) */
     double c[3], n[3];
+    HGO_FLOPS(3);
     v3_cross(r, fc + 3, c);
     n[0] = fc[0] + c[0]; n[1] = fc[1] + c[1]; n[2] = fc[2] + c[2];
     m3_tmulv(E, n, fp);
@@ -157,6 +179,7 @@ static void build_X(const double E[9], const double r[3], double X[36]) {
 /* symmetric positive definite 6x6 inverse via Cholesky */
 static int spd6_inverse(const double A[36], double Ainv[36]) {
     double L[36] = {0};
+    HGO_FLOPS(70 + 6 + 15 + 6 * 72);
     for (int i = 0; i < 6; i++)
         for (int j = 0; j <= i; j++) {
             double s = A[6 * i + j];
@@ -195,6 +218,7 @@ static void kinematics(const hg_model *m, const double *st, scratch_t *w) {
         m3_mul(Rq, m->R0[i], w->E[i]);
         m3_mulv(w->E[i], m->d[i], t);
         for (int k = 0; k < 3; k++) w->r[i][k] = m->e[i][k] + t[k];
+        HGO_FLOPS(6);
         memcpy(w->S[i], m->axis[i], 3 * sizeof(double));
         v3_cross(m->axis[i], m->e[i], w->S[i] + 3);
         const int p = m->parent[i] + 1;
@@ -231,6 +255,8 @@ static int aba(const hg_model *m, const hg_config *c, const double *st, const do
             for (int k = 0; k < 3; k++) cor[i][3 + k] = t1[k] + t2[k];
             for (int k = 0; k < 6; k++) v[b][k] += vj[k];
         }
+        HGO_FLOPS(b ? 6 + 3 + 6 : 0);       /* vj, cor linear part, v += vj */
+        HGO_FLOPS(3 + 2 + 12 + 24);         /* Iw, two sqrt, bias force */
         const double mass = b ? m->mass[i] : m->base_mass;
         const double *I = b ? m->inertia[i] : m->base_inertia;
         memset(IA[b], 0, sizeof IA[b]);
@@ -249,6 +275,7 @@ static int aba(const hg_model *m, const hg_config *c, const double *st, const do
     for (int i = n - 1; i >= 0; i--) {
         const int b = i + 1, p = m->parent[i] + 1;
         double D = 0, Ia[36], pa[6], X[36], T[36];
+        HGO_FLOPS(72 + 12 + 1 + 14 + 108 + 90 + 432 + 468 + 6);   /* U, D, 1/D, u, Ia, pa, Ia X, X^T (Ia X) +=, pA += */
         for (int r = 0; r < 6; r++) {
             double s = 0;
             for (int k = 0; k < 6; k++) s += IA[b][6 * r + k] * w->S[i][k];
@@ -283,6 +310,7 @@ static int aba(const hg_model *m, const hg_config *c, const double *st, const do
         for (int k = 0; k < 6; k++) pA[p][k] += fp[k];
     }
     if (spd6_inverse(IA[0], w->IAbase_inv)) return -1;
+    HGO_FLOPS(72 + 31 * n + 3);            /* base acceleration; per link of the root -> leaves pass: + cor, U.a, 1/D, S qdd */
     for (int r = 0; r < 6; r++) {
         double s = 0;
         for (int k = 0; k < 6; k++) s -= w->IAbase_inv[6 * r + k] * pA[0][k];
@@ -312,6 +340,7 @@ static void impulse_response(const hg_model *m, const scratch_t *w, const double
     double Z[NL + 1][6], Y[NL], a[NL + 1][6];
     memset(Z, 0, sizeof(double) * 6 * (n + 1));
     double t[3];
+    HGO_FLOPS((36 + 25) * n + 72);         /* per link: Y, Z + U Y / D, Z[p] +=  |  U.a, 1/D, S qdd;  base: 6x6 product */
     m3_tmulv(w->Rw[0], f, t);
     for (int k = 0; k < 3; k++) Z[0][k] = -t[k];
     m3_tmulv(w->Rw[0], f + 3, t);
@@ -346,11 +375,13 @@ static void impulse_response(const hg_model *m, const scratch_t *w, const double
 static void point_jacobian(const hg_model *m, const scratch_t *w, int body, const double pt[3],
                            const double dir[3], double sign, double *J) {
     double rel[3], c[3];
+    HGO_FLOPS(3 + 12);
     for (int k = 0; k < 3; k++) rel[k] = pt[k] - w->xw[0][k];
     v3_cross(rel, dir, c);
     for (int k = 0; k < 3; k++) { J[k] += sign * c[k]; J[3 + k] += sign * dir[k]; }
     for (int i = body; i >= 0; i = m->parent[i]) {
         double aw[3], ew[3], piv[3];
+        HGO_FLOPS(6 + 2);
         m3_mulv(w->Rw[i + 1], m->axis[i], aw);
         m3_mulv(w->Rw[i + 1], m->e[i], ew);
         for (int k = 0; k < 3; k++) piv[k] = pt[k] - (w->xw[i + 1][k] - ew[k]);
@@ -361,6 +392,7 @@ static void point_jacobian(const hg_model *m, const scratch_t *w, int body, cons
 
 /* Bullet's btPlaneSpace1: two unit tangents p, q orthogonal to n */
 static void plane_space(const double n[3], double p[3], double q[3]) {
+    HGO_FLOPS(12);
     if (fabs(n[2]) > 0.7071067811865475244) {
         double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a);
         p[0] = 0; p[1] = -n[2] * k; p[2] = n[1] * k;
@@ -389,6 +421,7 @@ static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_
         const int b = m->sphere_link[s] + 1;
         double t[3];
         m3_mulv(w->Rw[b], m->sphere_pos[s], t);
+        HGO_FLOPS(4);
         for (int k = 0; k < 3; k++) cw[s][k] = w->xw[b][k] + t[k];
         dist[s] = cw[s][2] - m->sphere_radius[s];
     }
@@ -414,9 +447,11 @@ static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_
         for (int p = 0; p < m->n_pairs && nc < maxc; p++) {
             const int a = m->pair_a[p], b = m->pair_b[p];
             double d[3] = {cw[a][0] - cw[b][0], cw[a][1] - cw[b][1], cw[a][2] - cw[b][2]};
+            HGO_FLOPS(3 + 1 + 2);
             const double len = sqrt(v3_dot(d, d));
             const double ds = len - m->sphere_radius[a] - m->sphere_radius[b];
             if (!(ds < c->contact_margin) || len < 1e-9) continue;
+            HGO_FLOPS(3 + 3 * 6);
             contact_t *k = &out[nc++];
             k->body_a = m->sphere_link[a]; k->body_b = m->sphere_link[b]; k->sphere_a = a; k->sphere_b = b;
             for (int j = 0; j < 3; j++) {
@@ -446,6 +481,7 @@ static void resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int 
         lo = -mu * tot; hi = mu * tot;
     }
     double jv = 0;
+    HGO_FLOPS(4 * ndof + 4 + (r->normal_row >= 0 ? 2 : 0));
     for (int k = 0; k < ndof; k++) jv += r->J[k] * dv[k];
     double dl = r->rhs - jv * r->diag_inv;
     double sum = r->lambda + dl;
@@ -489,6 +525,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
     const int nc = detect_contacts(m, c, &W, con);
     if (aba(m, c, st, NULL, &W, acc)) return -1;
 
+    HGO_FLOPS(2 * ndof);
     for (int k = 0; k < 3; k++) { st[10 + k] += dt * acc[k]; st[7 + k] += dt * acc[3 + k]; }
     for (int i = 0; i < n; i++) qd[i] += dt * acc[6 + i];
     clamp_velocities(c, st, n);
@@ -516,6 +553,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         memset(r->J, 0, sizeof(double) * ndof);
         r->J[6 + i] = lim_sign[k];
         impulse_response(m, &W, r->J, r->u);
+        HGO_FLOPS(8);
         r->diag_inv = 1.0 / (lim_sign[k] * r->u[6 + i]);
         r->rhs = (-lim_pen[k] * c->contact_erp / dt - lim_sign[k] * qd[i]) * r->diag_inv;
         r->lo = 0; r->hi = c->limit_max_impulse; r->lambda = 0; r->normal_row = -1;
@@ -525,6 +563,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         row_t *r = &rows[nr++];
         memset(r->J, 0, sizeof(double) * ndof);
         r->J[6 + i] = 1.0;
+        HGO_FLOPS(11);
         double target = c->kp * (tgt[i] - q[i]) / dt + qd[i] + c->kd * (0.0 - qd[i]);
         if (target > m->max_vel[i]) target = m->max_vel[i];
         if (target < -m->max_vel[i]) target = -m->max_vel[i];
@@ -542,6 +581,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         if (con[k].body_b >= -1) point_jacobian(m, &W, con[k].body_b, con[k].pt, con[k].n, -1.0, r->J);
         impulse_response(m, &W, r->J, r->u);
         double den = 0, rv = 0;
+        HGO_FLOPS(4 * ndof + 6);
         for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
         r->diag_inv = 1.0 / den;
         double pos_err = 0, vel_err = -rv;
@@ -561,6 +601,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
             if (con[k].body_b >= -1) point_jacobian(m, &W, con[k].body_b, con[k].pt, t[d], -1.0, r->J);
             impulse_response(m, &W, r->J, r->u);
             double den = 0, rv = 0;
+            HGO_FLOPS(4 * ndof + 2);
             for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
             r->diag_inv = 1.0 / den;
             r->rhs = -rv * r->diag_inv;
@@ -578,6 +619,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         for (int j = first_friction; j < nr; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
     }
 
+    HGO_FLOPS(ndof + 2 * (3 + n) + 60);    /* v += dv, positions, quaternion update */
     for (int k = 0; k < 3; k++) { st[10 + k] += dv[k]; st[7 + k] += dv[3 + k]; }
     for (int i = 0; i < n; i++) qd[i] += dv[6 + i];
     clamp_velocities(c, st, n);
@@ -645,6 +687,10 @@ static void apply_base_cmd(const hg_model *m, double *st, const double *cmd) {
 /* ================================================================== */
 /* exported API                                                        */
 /* ================================================================== */
+#ifdef HGO_COUNT_FLOPS
+void hgo_flops_reset(void) { hgo_flop_counter = 0.0; }
+double hgo_flops_read(void) { return hgo_flop_counter; }      /* of the calling thread: use n_envs <= 3 (no OpenMP team) */
+#endif
 void hgo_reset(const hg_model *m, double *state, int n_envs) {
     const int n = m->n_links, S = HG_STATE_SIZE(n);
     for (int e = 0; e < n_envs; e++) {

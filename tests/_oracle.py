@@ -68,6 +68,46 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
 
 
+def counted_flops_per_env_step(model: FlatModel, cfg: SimConfig, actions, joint_sel=None, n_substeps: int = 1,
+                               warmup: int = 0) -> dict:
+    """Flops that the oracle's formulation executes per env step, counted by the instrumented build
+    oracle/libhg_oracle_flops.so (-DHGO_COUNT_FLOPS): ONE env stepped through `actions` [T][n_sel]; the first
+    `warmup` steps are not counted (e.g. the fall onto the ground).  Returns {"flops_per_env_step", "mean_contacts"}."""
+    so = os.path.join(ROOT, "oracle", "libhg_oracle_flops.so")
+    src = os.path.join(ROOT, "oracle", "hg_oracle.c")
+    if (not os.path.exists(so)) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libhg_oracle_flops.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    L.hgo_reset.argtypes = [C.POINTER(HgModel), dp, C.c_int]
+    L.hgo_reset.restype = None
+    L.hgo_step.argtypes = lib().hgo_step.argtypes
+    L.hgo_step.restype = C.c_int
+    L.hgo_flops_read.restype = C.c_double
+    L.hgo_flops_reset.restype = None
+    cm, cc = model.to_c(), cfg.to_c()
+    n = model.n_links
+    state = np.zeros((1, HG_STATE_BASE + 3 * n))
+    L.hgo_reset(C.byref(cm), _dp(state), 1)
+    sel_p, n_sel = None, 0
+    if joint_sel is not None:
+        sel = np.ascontiguousarray(joint_sel, np.int32)
+        sel_p, n_sel = sel.ctypes.data_as(C.POINTER(C.c_int32)), len(sel)
+    nc = np.zeros(1, np.int32)
+    acts = np.ascontiguousarray(actions, np.float64)
+    contacts, counted = 0, 0
+    for t in range(len(acts)):
+        if t == warmup:
+            L.hgo_flops_reset()
+        rc = L.hgo_step(C.byref(cm), C.byref(cc), 1, _dp(state), _dp(acts[t].reshape(1, -1)), sel_p, n_sel, n_substeps,
+                        None, None, None, None, None, None, nc.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc:
+            raise RuntimeError(f"hgo_step failed: {rc}")
+        if t >= warmup:
+            contacts += int(nc[0]); counted += 1
+    return {"flops_per_env_step": L.hgo_flops_read() / max(counted, 1), "mean_contacts": contacts / max(counted, 1)}
+
+
 class OracleSim:
     """Batched FP64 CPU simulation with the same step semantics as the HIP library."""
 

@@ -240,3 +240,20 @@ def test_motor_torque_is_the_impulse_that_moved_the_robot(name):
     sim.state[:] = st1
     vel = np.concatenate([st1[0, 10:13], st1[0, 7:10], st1[0, 13 + n:13 + 2 * n]])   # (angular, linear, joints)
     assert np.abs(vel - dv).max() < 1e-9 * max(1.0, np.abs(dv).max()), np.abs(vel - dv).max()
+
+
+def test_counted_flops_agree_with_the_roofline_formula():
+    """SURVEY 8d asks for counted values from an instrumented build of the oracle in place of the estimated constants:
+    oracle/libhg_oracle_flops.so counts what the restatement executes; the formula that bench.py prices `valu` with
+     must stay within 20 % of it for all four robots."""
+    import bench
+    from _oracle import counted_flops_per_env_step
+    for name, sub in (("nao", 1), ("pepper", 1), ("romeo", 1), ("dancer", 4)):
+        model, cfg = load_robot(name)
+        idx = np.asarray(model.act_joint)
+        rng = np.random.default_rng(3)
+        acts = rng.uniform(np.maximum(model.lower[idx], -1), np.minimum(model.upper[idx], 1), (160, len(idx)))
+        r = counted_flops_per_env_step(model, cfg, acts, n_substeps=sub, warmup=80)
+        formula = bench.algorithmic_flops_per_env_step(model, cfg, n_contacts=r["mean_contacts"], n_substeps=sub)
+        assert r["flops_per_env_step"] > 0
+        assert abs(formula / r["flops_per_env_step"] - 1.0) < 0.2, (name, r, formula)
