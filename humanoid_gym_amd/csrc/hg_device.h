@@ -20,8 +20,8 @@ constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
 constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
 constexpr int CON   = 12;   // floats per contact record
-// the cache record of a link once it has been turned to world-aligned axes (hg_step.hip, 3b)
-constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10;
+// the cache record of a link (world-aligned axes, origin at the link's COM; hg_step.hip, phase 1)
+constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10, C_XW = 16, C_U = 19;
 
 // DevModel::link[i][...]
 enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTIA = 22,
@@ -91,7 +91,7 @@ struct StepOut {
 // LDS carve-up (offsets in floats) for a model with n links / ns spheres.
 // vel/F and lam/misc share storage (never live together); region AB is time-shared, see hg_step.hip.
 struct LdsPlan {
-    int cache, jw, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, rq, ys, AB, acc, total;
+    int cache, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, ys, AB, acc, total;
 };
 // With self-collision two more arrays exist, never live together, so they share one region: the world centres
 // (+ radius) of the n_self spheres that appear in pairs (contact detection), and the second-path Y values of
@@ -99,8 +99,7 @@ struct LdsPlan {
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 // Variants whose impulse-response pass keeps the own-path `Y` values (one per depth and lane) in LDS instead of
-// registers: DEPTH * WAVE floats laid over three arrays that are dead by then (joint axes / pivots, sphere
-// distances, link orientations).  For the shapes whose A-rows leave no registers for them: 12 contact slots (hipcc
+// registers: DEPTH * WAVE floats laid over an array that is dead by then (the sphere distances).  For the shapes whose A-rows leave no registers for them: 12 contact slots (hipcc
 // spilled them to scratch) and two rows per lane (NAO + fingers 6 % faster, Romeo + hands 4.5 %).  Measured on the
 // others too: NAO and Pepper within 1 %, Romeo 10 % slower (the extra 1.3 KB of LDS costs it a wave per SIMD).
 #ifndef HG_YS_LDS
@@ -118,12 +117,9 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.con = o;   o += CON * (nc3 / 3);
     p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
     p.tab = o;   o += rup4(n);              // byte tables (4 n bytes): next_sibling, base_children, first_child, lev_order
-    // three arrays that are dead once the rows are set up, and the Y values of the response pass laid over them
+    // the sphere - plane distances are dead once the contacts are found: the Y values of the response pass are laid over them
     p.ys = o;
-    p.jw = o;    o += 8 * n;                // world joint axes / pivots (kinematics -> contact Jacobians)
-    p.sdist = o; o += rup4(ns);             // sphere - plane distances (contact detection)
-    p.rq = o;    o += 4 * n;                // world orientation of every link as a quaternion, from the kinematics to the
-                                            // conversion of the ABA cache to world-aligned axes (hg_step.hip, 3b)
+    p.sdist = o; o += rup4(ns);
     o = imax(o, p.ys + ys);
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);

@@ -83,20 +83,11 @@ HG_FI void sym_rank1_sub(Sym3 &s, V3 u, float k) {
     s.yy = fmaf(-u.y * k, u.y, s.yy); s.yz = fmaf(-u.y * k, u.z, s.yz); s.zz = fmaf(-u.z * k, u.z, s.zz);
 }
 
-// spatial vector: angular part a, linear part l, in a body's internal frame
+// spatial vector: angular part a, linear part l (axes parallel to the world's, origin at a body's COM)
 struct Sv { V3 a, l; };
 HG_FI Sv operator+(Sv p, Sv q) { Sv r; r.a = p.a + q.a; r.l = p.l + q.l; return r; }
 HG_FI float sdot(Sv p, Sv q) { return dot(p.a, q.a) + dot(p.l, q.l); }
 HG_FI Sv sfma(Sv p, float s, Sv c) { Sv r; r.a = fma3(p.a, s, c.a); r.l = fma3(p.l, s, c.l); return r; }
-
-// motion vector parent frame -> child frame:  w' = E w ; v' = E v + w' x r
-HG_FI Sv xmotion(const M3 &E, V3 r, Sv p) {
-    Sv c; c.a = mulv(E, p.a); c.l = mulv(E, p.l) + cross(c.a, r); return c;
-}
-// force vector child frame -> parent frame:  f = E^T f_c ; n = E^T (n_c + r x f_c)
-HG_FI Sv xforce_up(const M3 &E, V3 r, Sv f) {
-    Sv p; p.a = tmulv(E, f.a + cross(r, f.l)); p.l = tmulv(E, f.l); return p;
-}
 
 // articulated inertia [[A, B], [B^T, C]], A and C symmetric
 struct AI { Sym3 A; M3 B; Sym3 C; };
@@ -106,29 +97,6 @@ HG_FI Sv ai_mul(const AI &I, Sv v) {
     f.l = tmulv(I.B, v.a) + symv(I.C, v.l);
     return f;
 }
-// X^T I X with X the motion transform parent -> child (E, r): result in the parent frame
-HG_FI AI ai_to_parent(const AI &I, const M3 &E, V3 r) {
-    const M3 Cf = full(I.C);
-    M3 Bp;   // B' = B + r~ C   (column j of r~ C is r x C_col_j; C is symmetric)
-    {
-        const V3 n0 = cross(r, row(Cf, 0)), n1 = cross(r, row(Cf, 1)), n2 = cross(r, row(Cf, 2));
-        Bp.m[0] = I.B.m[0] + n0.x; Bp.m[1] = I.B.m[1] + n1.x; Bp.m[2] = I.B.m[2] + n2.x;
-        Bp.m[3] = I.B.m[3] + n0.y; Bp.m[4] = I.B.m[4] + n1.y; Bp.m[5] = I.B.m[5] + n2.y;
-        Bp.m[6] = I.B.m[6] + n0.z; Bp.m[7] = I.B.m[7] + n1.z; Bp.m[8] = I.B.m[8] + n2.z;
-    }
-    // A'[i][j] = A[i][j] + (r x Brow_i)[j] + (r x B'row_j)[i]
-    const V3 c0 = cross(r, row(I.B, 0)), c1 = cross(r, row(I.B, 1)), c2 = cross(r, row(I.B, 2));
-    const V3 d0 = cross(r, row(Bp, 0)), d1 = cross(r, row(Bp, 1)), d2 = cross(r, row(Bp, 2));
-    Sym3 Ap;
-    Ap.xx = I.A.xx + c0.x + d0.x; Ap.xy = I.A.xy + c0.y + d1.x; Ap.xz = I.A.xz + c0.z + d2.x;
-    Ap.yy = I.A.yy + c1.y + d1.y; Ap.yz = I.A.yz + c1.z + d2.y; Ap.zz = I.A.zz + c2.z + d2.z;
-    AI o;
-    o.A = symm(tmul(E, mul(full(Ap), E)));
-    o.B = tmul(E, mul(Bp, E));
-    o.C = symm(tmul(E, mul(Cf, E)));
-    return o;
-}
-
 HG_FI M3 quat_to_mat(float x, float y, float z, float w) {
     M3 R;
     R.m[0] = 1 - 2 * (y * y + z * z); R.m[1] = 2 * (x * y - z * w);     R.m[2] = 2 * (x * z + y * w);

@@ -7,6 +7,8 @@
 // articulated-body algorithm, motor + contact rows, projected Gauss-Seidel,
 // integration } -> observations and contact flags.
 //
+// Every per-link quantity (velocity, inertia, bias force, U, S, acceleration, impulse response) is expressed in axes
+// parallel to the world's with the origin at the link's own COM: parent <-> child transforms are translations.
 // Lane roles change per phase (FP32 VALU throughout, no MFMA: the operands are
 // 3x3 / 6x6 blocks of a tree recursion, not GEMM tiles):
 //   * kinematics and the root -> leaves ABA pass: lane i owns link i; the tree is swept level by
@@ -136,7 +138,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     L.acc = __builtin_amdgcn_readfirstlane(L.acc);
     static_assert(DEPTH <= DMAX, "path words hold DMAX levels");
     float *const cacheL = lds + L.cache;
-    float *const jwL = lds + L.jw;
     float *const baseL = lds + L.base;     // [0:9) Rw0  [9:12) xw0  [12:48) IA0^-1
     float *const velL = lds + L.vel;
     float *const FL = lds + L.F;
@@ -151,7 +152,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     signed char *const fchL = nsibL + 2 * n;                                     // first_child[n]
     signed char *const ordL = nsibL + 3 * n;                                     // links sorted by level
     float *const ysL = lds + L.ys;
-    float *const rqL = lds + L.rq;                                               // world orientation quaternion of every link
     // region AB is time-shared: kinematics exchange (pub) -> child-to-parent ABA exchange (up)
     // -> contact Jacobians (Jc) -> 6-float exchanges of the final response
     float *const pubL = lds + L.AB;                       // PUB * (n+1), entry n = base
@@ -237,9 +237,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         float q = 0.f, qd = 0.f;
         if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
         // ============ 1. kinematics, root -> leaves ============================================
+        // Every per-link quantity of the step (velocities, inertias, bias forces, the ABA cache, the impulse responses)
+        // is expressed in axes PARALLEL TO THE WORLD'S with the origin at the link's own COM.  The transform between a
+        // link and its parent is then a pure translation by r_w (6 VALU where a joint transform costs 24), gravity
+        // needs no rotation, and origins stay at the COMs, so nothing cancels that would not cancel in link frames.
+        // Cache record of a link: [0:3) r_w parent COM -> link COM, [3] 1/D, [4:10) U, [10:16) S, [16:19) COM, [19] u,
+        // [26], [27] motor limits.
         const V3 ax = ld3(lk + L_AXIS);
-        const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace
-        Sv Sm; Sm.a = ax; Sm.l = sl;
+        const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace (link frame)
         M3 E; V3 r;
         {
             float sq, cq;
@@ -247,12 +252,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             E = mul(axis_rot(ax, sq, cq), ldm(lk + L_R0));
             r = ld3(lk + L_E) + mulv(E, ld3(lk + L_D));
         }
-        if (is_link) {     // joint transform and motion subspace of every link, read by all later sweeps
+        if (is_link) {
             float *pc = cacheL + CACHE * lane;
-            stm(pc, E); st3(pc + 9, r); stsv(pc + 20, Sm);
             pc[26] = lk[L_MAXVEL]; pc[27] = lk[L_MAXIMP];      // motor-row limits, read in phase 4
         }
-        Sv v0;
+        Sv v0;      // base velocity: world axes, at the base COM (as the state record keeps it)
         {
             const V3 bpos = ld3(st);
             V3 bvel = ld3(st + 7), bang = ld3(st + 10);
@@ -269,7 +273,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 bvel = v3(cy * cmd.x - sy * cmd.y, sy * cmd.x + cy * cmd.y, 0.f);
                 bang = v3(0.f, 0.f, cmd.z);
             }
-            v0.a = tmulv(Rw0, bang); v0.l = tmulv(Rw0, bvel);
+            v0.a = bang; v0.l = bvel;
             if (lane == 0) {
                 float *pb = pubL + PUB * n;
                 stm(pb, Rw0); st3(pb + 9, bpos); stsv(pb + 12, v0);
@@ -281,10 +285,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         wave_sync();
         HG_TICK(2);
-        Sv v = v0;
-        V3 gl = v3(0, 0, 0);                   // gravity in the link frame
-        M3 Rw;                                 // world orientation of this lane's link
-        V3 xw = v3(0, 0, 0);                   // its COM
+        Sv v = v0;                             // spatial velocity of this lane's link
+        Sv Sw; Sw.a = v3(0, 0, 0); Sw.l = v3(0, 0, 0);     // its motion subspace
+        V3 rw = v3(0, 0, 0), xw = v3(0, 0, 0); // parent COM -> COM, COM
+        M3 Rw;                                 // world orientation
 #pragma unroll
         for (int k = 0; k < 9; k++) Rw.m[k] = (k % 4 == 0) ? 1.f : 0.f;
         #pragma unroll 1
@@ -292,23 +296,20 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             if (is_link && mylev == lev) {
                 const float *pp = pubL + PUB * pidx;
                 Rw = mul_bt(ldm(pp), E);
-                xw = ld3(pp + 9) + mulv(Rw, r);
-                v = sfma(Sm, qd, xmotion(E, r, ldsv(pp + 12)));
+                rw = mulv(Rw, r);
+                xw = ld3(pp + 9) + rw;
+                Sw.a = mulv(Rw, ax); Sw.l = mulv(Rw, sl);
+                const Sv vp = ldsv(pp + 12);
+                v.a = fma3(Sw.a, qd, vp.a);
+                v.l = fma3(Sw.l, qd, vp.l + cross(vp.a, rw));
                 float *po = pubL + PUB * lane;
                 stm(po, Rw); st3(po + 9, xw); stsv(po + 12, v);
             }
             wave_sync();
         }
         if (is_link) {       // once per link, after the sweep
-            gl = tmulv(Rw, v3(P.gx, P.gy, P.gz));
-            // world-frame joint axis and pivot for the contact Jacobians
-            float *pj = jwL + 8 * lane;
-            st3(pj, mulv(Rw, ax));
-            st3(pj + 4, xw - mulv(Rw, ld3(lk + L_E)));
-            // world orientation, kept (4 floats) until the ABA cache is turned to world-aligned axes in 3b
-            float qq[4];
-            mat_to_quat(Rw, qq);
-            *reinterpret_cast<float4 *>(rqL + 4 * lane) = make_float4(qq[0], qq[1], qq[2], qq[3]);
+            float *pc = cacheL + CACHE * lane;
+            st3(pc + C_RW, rw); stsv(pc + C_SW, Sw); st3(pc + C_XW, xw);
         }
 
         HG_TICK(3);
@@ -408,7 +409,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // Prelude, lane = link: velocity-product acceleration and bias force.  The link's own `up`
         // record carries its rigid-body inertia and bias force until the sweep overwrites it.
         if (is_link) {
-            Sv vj; vj.a = ax * qd; vj.l = sl * qd;
+            Sv vj; vj.a = Sw.a * qd; vj.l = Sw.l * qd;
             // v already contains vj; v x vj == (v - vj) x vj + 0, use v directly (vj x vj = 0 for the
             // angular part; the linear part keeps both terms)
             Sv cor, pA;
@@ -416,12 +417,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             cor.l = cross(v.a, vj.l) + cross(v.l, vj.a);
             const float mass = lk[L_MASS];
             const V3 inertia = ld3(lk + L_INERTIA);
-            const V3 Iw = v3(inertia.x * v.a.x, inertia.y * v.a.y, inertia.z * v.a.z);
+            // rotational inertia in world axes: Rw diag(I) Rw^T
+            Sym3 Iw;
+            {
+                const V3 r0 = row(Rw, 0), r1 = row(Rw, 1), r2 = row(Rw, 2);
+                const V3 s0 = v3(r0.x * inertia.x, r0.y * inertia.y, r0.z * inertia.z);
+                const V3 s1 = v3(r1.x * inertia.x, r1.y * inertia.y, r1.z * inertia.z);
+                const V3 s2 = v3(r2.x * inertia.x, r2.y * inertia.y, r2.z * inertia.z);
+                Iw.xx = dot(s0, r0); Iw.xy = dot(s0, r1); Iw.xz = dot(s0, r2);
+                Iw.yy = dot(s1, r1); Iw.yz = dot(s1, r2); Iw.zz = dot(s2, r2);
+            }
+            const V3 Iom = symv(Iw, v.a);
             const float wn = sqrtf(dot(v.a, v.a)), vn = sqrtf(dot(v.l, v.l));
-            pA.a = cross(v.a, Iw) + Iw * (P.ang_damp + P.ang_damp * wn);
-            pA.l = (cross(v.a, v.l) - gl + v.l * (P.lin_damp + P.lin_damp * vn)) * mass;
+            pA.a = cross(v.a, Iom) + Iom * (P.ang_damp + P.ang_damp * wn);
+            pA.l = (cross(v.a, v.l) - v3(P.gx, P.gy, P.gz) + v.l * (P.lin_damp + P.lin_damp * vn)) * mass;
             float *pu = upL + UP * lane;
-            st3(pu, inertia); pu[3] = mass; pu[4] = -lk[L_DAMP] * qd;
+            pu[0] = Iw.xx; pu[1] = Iw.xy; pu[2] = Iw.xz; pu[3] = Iw.yy; pu[4] = Iw.yz; pu[5] = Iw.zz;
+            pu[6] = mass; pu[7] = -lk[L_DAMP] * qd;
             stsv(pu + 21, pA);
             stsv(accL + 8 * lane, cor);      // read back in the downward pass
         }
@@ -445,11 +457,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         float *pc = cacheL + CACHE * link;
                         float *own = upL + UP * link;
                         AI IA;
-                        IA.A.xx = own[0]; IA.A.yy = own[1]; IA.A.zz = own[2]; IA.A.xy = IA.A.xz = IA.A.yz = 0.f;
-                        IA.C.xx = IA.C.yy = IA.C.zz = own[3]; IA.C.xy = IA.C.xz = IA.C.yz = 0.f;
+                        IA.A.xx = own[0]; IA.A.xy = own[1]; IA.A.xz = own[2]; IA.A.yy = own[3]; IA.A.yz = own[4]; IA.A.zz = own[5];
+                        IA.C.xx = IA.C.yy = IA.C.zz = own[6]; IA.C.xy = IA.C.xz = IA.C.yz = 0.f;
 #pragma unroll
                         for (int j = 0; j < 9; j++) IA.B.m[j] = 0.f;
-                        const float tau0 = own[4];
+                        const float tau0 = own[7];
                         Sv pA = ldsv(own + 21);
                         #pragma unroll 1
                         for (int c = fchL[link]; c >= 0; c = nsibL[c]) {
@@ -460,9 +472,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                             IA.C.xx += pu[15]; IA.C.xy += pu[16]; IA.C.xz += pu[17]; IA.C.yy += pu[18]; IA.C.yz += pu[19]; IA.C.zz += pu[20];
                             pA = pA + ldsv(pu + 21);
                         }
-                        const M3 E = ldm(pc);
-                        const V3 r = ld3(pc + 9);
-                        const Sv Sm = ldsv(pc + 20);
+                        const V3 r = ld3(pc + C_RW);
+                        const Sv Sm = ldsv(pc + C_SW);
                         const Sv U = ai_mul(IA, Sm);
                         const float Dinv = __frcp_rn(sdot(Sm, U));      // v_rcp_f32, 1 ulp
                         const float u = tau0 - sdot(Sm, pA);
@@ -472,18 +483,18 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                             w = ldsv(accL + 8 * link);
                         } else {
                             const int m = k < 3 ? k : k - 3;
-                            const V3 col = v3(pc[m], pc[3 + m], pc[6 + m]);          // E e_m (lane-variant m: read from LDS, not registers)
+                            const V3 col = v3(m == 0 ? 1.f : 0.f, m == 1 ? 1.f : 0.f, m == 2 ? 1.f : 0.f);      // the transform is a translation
                             if (k < 3) { w.a = col; w.l = cross(col, r); }
                             else { w.a = v3(0, 0, 0); w.l = col; }
                         }
                         const float t = sdot(U, w) * Dinv;
                         Sv f = sfma(U, -t, ai_mul(IA, w));
                         if (k == 6) f = sfma(U, u * Dinv, f + pA);
-                        const Sv o = xforce_up(E, r, f);
+                        Sv o; o.a = f.a + cross(r, f.l); o.l = f.l;      // to the parent's origin
                         // all reads of the own record are issued: overwrite it with the parent-frame data
                         if (k == 6) {
                             stsv(own + 21, o);
-                            stsv(pc + 12, U); pc[18] = Dinv; pc[19] = u;
+                            stsv(pc + C_UW, U); pc[C_DINV] = Dinv; pc[C_U] = u;
                         } else {
                             // column k of X^T Ia X; the packed record keeps rows <= column of A and C, and B by rows
                             const int m = k < 3 ? k : k - 3;
@@ -500,7 +511,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         HG_TICK(5);
-        // base (every lane computes the same thing; results stay in registers)
+        // base, in world axes at its COM (every lane computes the same thing; results stay in registers)
         Sv a0;
         {
             float A6[36];
@@ -510,9 +521,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const V3 binertia = ld3(M->base + B_INERTIA);
             const M3 Rw0 = ldm(baseL);
             const Sv v0 = ldsv(baseL + 52);
-            A6[0] = binertia.x; A6[7] = binertia.y; A6[14] = binertia.z; A6[21] = A6[28] = A6[35] = bmass;
-            const V3 Iw = v3(binertia.x * v0.a.x, binertia.y * v0.a.y, binertia.z * v0.a.z);
-            const V3 g = tmulv(Rw0, v3(P.gx, P.gy, P.gz));
+            {   // rotational inertia in world axes
+                const V3 r0 = row(Rw0, 0), r1 = row(Rw0, 1), r2 = row(Rw0, 2);
+                const V3 s0 = v3(r0.x * binertia.x, r0.y * binertia.y, r0.z * binertia.z);
+                const V3 s1 = v3(r1.x * binertia.x, r1.y * binertia.y, r1.z * binertia.z);
+                const V3 s2 = v3(r2.x * binertia.x, r2.y * binertia.y, r2.z * binertia.z);
+                A6[0] = dot(s0, r0); A6[1] = dot(s0, r1); A6[2] = dot(s0, r2);
+                A6[7] = dot(s1, r1); A6[8] = dot(s1, r2); A6[14] = dot(s2, r2);
+            }
+            A6[21] = A6[28] = A6[35] = bmass;
+            const V3 Iw = v3(fmaf(A6[0], v0.a.x, fmaf(A6[1], v0.a.y, A6[2] * v0.a.z)),
+                             fmaf(A6[1], v0.a.x, fmaf(A6[7], v0.a.y, A6[8] * v0.a.z)),
+                             fmaf(A6[2], v0.a.x, fmaf(A6[8], v0.a.y, A6[14] * v0.a.z)));
+            const V3 g = v3(P.gx, P.gy, P.gz);
             const float wn = sqrtf(dot(v0.a, v0.a)), vn = sqrtf(dot(v0.l, v0.l));
             Sv p0;
             p0.a = cross(v0.a, Iw) + Iw * (P.ang_damp + P.ang_damp * wn);
@@ -569,43 +590,24 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if (mylev == lev) {
                     const float *pc = cacheL + CACHE * lane_p;
                     float *pa = accL + 8 * lane_p;
-                    Sv a = xmotion(ldm(pc), ld3(pc + 9), ldsv(accL + 8 * pidx)) + ldsv(pa);
-                    qdd = (pc[19] - sdot(ldsv(pc + 12), a)) * pc[18];
-                    a = sfma(ldsv(pc + 20), qdd, a);
+                    Sv a = ldsv(accL + 8 * pidx);
+                    a.l = a.l + cross(a.a, ld3(pc + C_RW));      // the parent's acceleration at this link's origin
+                    a = a + ldsv(pa);
+                    qdd = (pc[C_U] - sdot(ldsv(pc + C_UW), a)) * pc[C_DINV];
+                    a = sfma(ldsv(pc + C_SW), qdd, a);
                     stsv(pa, a);
                 }
                 wave_sync();
             }
         }
-        // ============ 3b. the ABA cache in world-aligned axes ===================================
-        // From here on (impulse responses of the rows, final response) every link's quantities are used in axes
-        // parallel to the world's with the origin at the link's own COM: the transform between a link and its parent
-        // is then a pure translation by r_w (6 VALU where the joint transform E costs 24, 16 floats per link
-        // from LDS instead of 25), and origins stay where they were, so nothing cancels that did not cancel before.
-        // Record: [0:3) r_w parent COM -> link COM, [3] 1/D, [4:10) U_w, [10:16) S_w; [26], [27] motor limits as before.
-        if (is_link) {
-            float *pc = cacheL + CACHE * lane;
-            const float4 qv = *reinterpret_cast<const float4 *>(rqL + 4 * lane);
-            const M3 Rl = quat_to_mat(qv.x, qv.y, qv.z, qv.w);
-            const V3 rl = ld3(pc + 9);
-            const Sv Ul = ldsv(pc + 12), Sl = ldsv(pc + 20);
-            const float Dinv = pc[18];
-            Sv Uw, Sw;
-            Uw.a = mulv(Rl, Ul.a); Uw.l = mulv(Rl, Ul.l);
-            Sw.a = mulv(Rl, Sl.a); Sw.l = mulv(Rl, Sl.l);
-            st3(pc + C_RW, mulv(Rl, rl)); pc[C_DINV] = Dinv;
-            stsv(pc + C_UW, Uw); stsv(pc + C_SW, Sw);
-        }
-        wave_sync();
         HG_TICK(6);
         // velocities += dt * unconstrained acceleration
         // (every velocity coordinate is clamped to +-vmax after each update, as btMultiBody does)
         qd = clampv(fmaf(P.dt, qdd, qd), P.vmax);
         {
-            const M3 Rw0 = ldm(baseL);
             const Sv v0 = ldsv(baseL + 52);
-            const V3 bang = clamp3(ld3(baseL + 58) + mulv(Rw0, a0.a) * P.dt, P.vmax);
-            const V3 bvel = clamp3(ld3(baseL + 61) + mulv(Rw0, a0.l + cross(v0.a, v0.l)) * P.dt, P.vmax);
+            const V3 bang = clamp3(ld3(baseL + 58) + a0.a * P.dt, P.vmax);
+            const V3 bvel = clamp3(ld3(baseL + 61) + (a0.l + cross(v0.a, v0.l)) * P.dt, P.vmax);      // classical acceleration of the COM
             // ============ 4. constraint rows ===================================================
             // current velocities for the contact rows
             if (lane == 0) { st3(velL, bang); st3(velL + 3, bvel); }
@@ -682,8 +684,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     if (dd <= maxlev) {      // wave-uniform
                         const int l = (int)((RC.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                         if (l >= 0) {
-                            const float *pj = jwL + 8 * l;
-                            const float j = dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                            const float *pcl = cacheL + CACHE * l;      // velocity of the point per unit joint rate: S.a x (pt - COM) + S.l
+                            const Sv Sl = ldsv(pcl + C_SW);
+                            const float j = dot(Sl.a, cross(pt - ld3(pcl + C_XW), dir)) + dot(Sl.l, dir);
                             JcL[(6 + l) * NC3 + col] = j;
                             rv = fmaf(j, velL[6 + l], rv);
                         }
@@ -696,8 +699,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         if (dd <= maxlev) {
                             const int l = (int)((RC.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                             if (l >= 0) {
-                                const float *pj = jwL + 8 * l;
-                                const float j = -dot(ld3(pj), cross(pt - ld3(pj + 4), dir));
+                                const float *pcl = cacheL + CACHE * l;
+                                const Sv Sl = ldsv(pcl + C_SW);
+                                const float j = -(dot(Sl.a, cross(pt - ld3(pcl + C_XW), dir)) + dot(Sl.l, dir));
                                 JcL[(6 + l) * NC3 + col] += j;
                                 rv = fmaf(j, velL[6 + l], rv);
                             }
@@ -870,13 +874,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 Z = Z + Z2;
             }
             // (ii) base
-            // (Z arrives in world axes at the base COM; the base's inverse inertia is kept in its body frame)
-            const M3 Rb = ldm(baseL);
-            Z.a = tmulv(Rb, Z.a - R.Jang);
-            Z.l = tmulv(Rb, Z.l - R.Jlin);
-            const Sv abb = neg_mul6(baseL + 12, Z);      // IA0^-1 streamed from LDS
-            const V3 uba = mulv(Rb, abb.a), ubl = mulv(Rb, abb.l);
-            Sv ab; ab.a = uba; ab.l = ubl;               // world axes
+            Z.a = Z.a - R.Jang;
+            Z.l = Z.l - R.Jlin;
+            const Sv ab = neg_mul6(baseL + 12, Z);       // IA0^-1 (world axes, at the base COM) streamed from LDS
+            const V3 uba = ab.a, ubl = ab.l;
             xdiag = dot(uba, R.Jang) + dot(ubl, R.Jlin);
             if (nc > 0) {
                 const float ub[6] = {uba.x, uba.y, uba.z, ubl.x, ubl.y, ubl.z};
@@ -1318,7 +1319,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             const Sv U = ldsv(pcm + C_UW);
             const float Dinv = pcm[C_DINV];
             const Sv Sm = ldsv(pcm + C_SW);
-            const M3 Rw0 = ldm(baseL);
             #pragma unroll 1
             for (int lev = maxlev; lev >= 1; --lev) {
                 if (is_link && mylev == lev) {
@@ -1335,10 +1335,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             Sv Z0; Z0.a = v3(0, 0, 0); Z0.l = v3(0, 0, 0);
             #pragma unroll 1
             for (int k = 0; k < nbc; ++k) Z0 = Z0 + ldsv(up6 + 8 * bchL[k]);
-            Z0.a = tmulv(Rw0, Z0.a - ld3(FL));
-            Z0.l = tmulv(Rw0, Z0.l - ld3(FL + 3));
-            const Sv abb = neg_mul6(baseL + 12, Z0);
-            Sv ab; ab.a = mulv(Rw0, abb.a); ab.l = mulv(Rw0, abb.l);      // world axes
+            Z0.a = Z0.a - ld3(FL);
+            Z0.l = Z0.l - ld3(FL + 3);
+            const Sv ab = neg_mul6(baseL + 12, Z0);
             if (lane == 0) stsv(pub6 + 8 * n, ab);
             wave_sync();
             float dq = 0.f;

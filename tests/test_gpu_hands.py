@@ -9,7 +9,7 @@ import pytest
 
 from humanoid_gym_amd.robots import load_robot
 from _oracle import OracleSim
-from test_gpu_parity import IntParity
+from test_gpu_parity import FloatParity, IntParity
 
 pytestmark = pytest.mark.gpu
 
@@ -76,7 +76,7 @@ def test_hands_one_step_parity_from_shared_states(name, steps, cfg_kw):
     # every dof gets a target (fingers too): sel = all dofs
     sel = np.arange(n, dtype=np.int32)
     lo, hi = np.maximum(model.lower, -1.5), np.minimum(model.upper, 1.5)
-    ip, worst_q, worst_qd, worst_tau, saw_contacts, saw_self = IntParity(), 0.0, 0.0, 0.0, 0, 0
+    ip, fp, saw_contacts, saw_self = IntParity(), FloatParity(1e-4, 0.03, 5e-3), 0, 0
     for t in range(steps):
         if t % 12 == 0:
             act = rng.uniform(lo, hi, (n_envs, n)).astype(np.float32).astype(np.float64)
@@ -94,18 +94,16 @@ def test_hands_one_step_parity_from_shared_states(name, steps, cfg_kw):
         gcol = gpu.collision.cpu().numpy()
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask, gcol):
-                worst_q = max(worst_q, float(np.abs(st[e, 13:13 + n] - cpu.q[e]).max()))
-                worst_qd = max(worst_qd, float(np.abs(st[e, 13 + n:13 + 2 * n] - cpu.qd[e]).max()))
                 scale = max(1.0, float(np.abs(o["motor_torque"][e]).max()))
-                worst_tau = max(worst_tau, float(np.abs(tau[e] - o["motor_torque"][e]).max()) / scale)
-        assert np.abs(st[:, :3] - cpu.state[:, :3]).max() < 1e-4
+                before = len(fp.outliers)
+                fp.add(o["n_contacts"][e], float(np.abs(st[e, 13:13 + n] - cpu.q[e]).max()),
+                       float(np.abs(st[e, 13 + n:13 + 2 * n] - cpu.qd[e]).max()),
+                       float(np.abs(tau[e] - o["motor_torque"][e]).max()) / scale)
+                if len(fp.outliers) == before:
+                    assert np.abs(st[e, :3] - cpu.state[e, :3]).max() < 1e-4
     ip.report(f"{name} {cfg_kw}")
-    print(f"[hands] {name} {cfg_kw}: {saw_contacts} contact rows ({saw_self} link-link), worst |dq| {worst_q:.2e} rad, "
-          f"|dqd| {worst_qd:.2e} rad/s, torque {worst_tau:.2e} (relative)")
+    fp.report(f"{name} {cfg_kw}: {saw_contacts} contact rows ({saw_self} link-link)")
     assert saw_contacts > 0
-    assert worst_q < 1e-4, worst_q
-    assert worst_qd < 0.03, worst_qd
-    assert worst_tau < 5e-3, worst_tau
 
 
 @pytest.mark.parametrize("name,n_violate", [("nao_hands", 1), ("nao_hands", 6), ("romeo_hands", 3), ("romeo_hands", 9)])
@@ -147,10 +145,10 @@ def test_hands_joint_limit_rows(name, n_violate):
 @pytest.mark.parametrize("gen,over,steps", [
     (dict(n_links=50, max_depth=10, n_chains=6, branch_at=((0, 2), (3, 4)), seed=21), dict(max_contacts=8), 150),               # 74 rows
     (dict(n_links=62, max_depth=12, n_chains=6, branch_at=((1, 3),), seed=22), dict(max_contacts=8), 150),                      # the largest tree: 86 rows
-    # 69 rows with link-link pairs.  120 steps: later one env of this tree is flung about at 25-65 rad/s by two
-    # interpenetrating boxes and a single step then differs by 3e-4 rad -- in the one-row-per-lane variant
-    # (max_contacts=6) just the same, 0.04 rad there: conditioning of that state, not of a kernel variant.
-    (dict(n_links=45, max_depth=9, n_chains=5, seed=23), dict(max_contacts=8, enable_self=True), 120),
+    # 69 rows with link-link pairs.  Late in the run one env of this tree is flung about at 25-65 rad/s by two
+    # interpenetrating boxes and single steps then differ by 3e-4 .. 4e-2 rad in every kernel variant: the kind of
+    # sample FloatParity counts as an outlier (test_gpu_parity.py).
+    (dict(n_links=45, max_depth=9, n_chains=5, seed=23), dict(max_contacts=8, enable_self=True), 150),
     (dict(n_links=40, max_depth=8, n_chains=6, seed=24), dict(max_contacts=12), 150),                                           # catch-all variant: 40 + 36 rows
 ])
 def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
@@ -169,7 +167,7 @@ def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
     gpu, cpu = HgSim(model, cfg, n_envs, "cuda:0"), OracleSim(model, cfg, n_envs)
     rng = np.random.default_rng(200 + gen["seed"])
     cpu.state[:, 7:13] = rng.uniform(-0.5, 0.5, (n_envs, 6))
-    ip, worst_q, contacts = IntParity(), 0.0, 0
+    ip, fp, contacts = IntParity(), FloatParity(2e-4), 0
     for t in range(steps):
         if t % 15 == 0:
             act = rng.uniform(-1.0, 1.0, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
@@ -183,10 +181,10 @@ def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
         contacts += int(o["n_contacts"].sum())
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask):
-                worst_q = max(worst_q, float(np.abs(gq[e] - o["q"][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()))
     ip.report(f"large tree {gen['n_links']} links")
+    fp.report(f"large tree {gen['n_links']} links")
     assert contacts > 0
-    assert worst_q < 2e-4, worst_q
     assert np.isfinite(cpu.state).all()
 
 

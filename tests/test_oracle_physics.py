@@ -153,10 +153,13 @@ def test_oracle_reproduces_committed_trajectories(fixture):
         model, cfg = load_robot("dancer")
         sim = OracleSim(model, cfg, 2)
         for t in range(z["actions"].shape[0]):
+            sim.state[:] = sim.state.astype(np.float32)          # one-step vectors: the stored state is what the next step starts from
+            np.testing.assert_array_equal(sim.state.astype(np.float32), z["state"][t])
             o = sim.step(z["actions"][t].astype(np.float64))
             assert np.abs(o["q"] - z["q"][t]).max() < 1e-9
             np.testing.assert_array_equal(o["n_contacts"], z["n_contacts"][t])
             np.testing.assert_array_equal(o["link_mask"], z["link_mask"][t])
+            np.testing.assert_array_equal(o["pairs"], z["pairs"][t])
     else:
         model, cfg = load_robot("nao")
         if fixture.endswith("free"):
