@@ -16,12 +16,15 @@ constexpr int WAVE  = 64;
 constexpr int DMAX  = 12;   // deepest supported link (base children are depth 1)
 constexpr int NSLOT = 2;    // saved-acceleration slots = deepest nesting of branching links (slots are recycled)
 constexpr int LINKC = 32;   // floats per link in DevModel::link
-constexpr int CACHE = 28;   // floats per link in the LDS articulated-body cache
+// floats per link in the LDS articulated-body cache: 22 used, records 16-byte aligned.  28 (stride of 8 distinct LDS
+// banks for the lane = link accesses) unless the model is so large that LDS bounds the occupancy: 24 lets a Romeo with
+// hands (61 links) run 8 instead of 6 waves per CU (+10 %); on Pepper 24 is 1.4 % slower than 28, on NAO 0.7 % faster.
+__host__ __device__ constexpr int cache_stride(int nmx) { return nmx > 48 ? 24 : 28; }
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
 constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
 constexpr int CON   = 12;   // floats per contact record
 // the cache record of a link (world-aligned axes, origin at the link's COM; hg_step.hip, phase 1)
-constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10, C_XW = 16, C_U = 19;
+constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10, C_XW = 16, C_U = 19, C_MAXVEL = 20, C_MAXIMP = 21;
 
 // DevModel::link[i][...]
 enum { L_R0 = 0, L_AXIS = 9, L_S = 12, L_D = 15, L_E = 18, L_MASS = 21, L_INERTIA = 22,
@@ -106,11 +109,11 @@ __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 #define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 || (nmx) + 3 * (maxc) > 64)
 #endif
 __host__ __device__ constexpr int ys_floats(int nmx, int maxc, int depth) { return HG_YS_LDS(nmx, maxc, depth) ? depth * WAVE : 0; }
-__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows, int ys) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows, int ys, int cstride) {
     LdsPlan p;
     int o = 0;
     const int ndof = rup4(6 + n);
-    p.cache = o; o += CACHE * n;
+    p.cache = o; o += cstride * n;
     p.base = o;  o += 64;
     p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
     p.lam = o;   p.misc = o; o += nrows > WAVE ? WAVE + rup4(nc3) : WAVE;      // impulses of all rows (two rows per lane beyond 64)

@@ -507,7 +507,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
     s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self,
                                                        kVariants[variant].nmx + 3 * kVariants[variant].maxc,
-                                                       ys_floats(kVariants[variant].nmx, kVariants[variant].maxc, kVariants[variant].depth)).total;
+                                                       ys_floats(kVariants[variant].nmx, kVariants[variant].maxc, kVariants[variant].depth),
+                                                       cache_stride(kVariants[variant].nmx)).total;
 
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_stride);

@@ -131,7 +131,8 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int ns = P.n_spheres;
     const int maxlev = P.maxlev;
     constexpr bool YSL = ys_floats(NMX, MAXC, DEPTH) > 0;      // own-path Y values of the response pass in LDS (hg_device.h)
-    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self, NROWS, ys_floats(NMX, MAXC, DEPTH));
+    constexpr int CACHE = cache_stride(NMX);                   // floats per link in the ABA cache
+    LdsPlan L = lds_plan(n, ns, NC3, maxlev, P.n_self, NROWS, ys_floats(NMX, MAXC, DEPTH), CACHE);
     // wave-uniform offsets: pin them to scalar registers (v_max3 and friends would otherwise
     // leave them in VGPRs that stay live for the whole kernel)
     L.AB = __builtin_amdgcn_readfirstlane(L.AB);
@@ -242,7 +243,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // link and its parent is then a pure translation by r_w (6 VALU where a joint transform costs 24), gravity
         // needs no rotation, and origins stay at the COMs, so nothing cancels that would not cancel in link frames.
         // Cache record of a link: [0:3) r_w parent COM -> link COM, [3] 1/D, [4:10) U, [10:16) S, [16:19) COM, [19] u,
-        // [26], [27] motor limits.
+        // [20], [21] motor limits.
         const V3 ax = ld3(lk + L_AXIS);
         const V3 sl = ld3(lk + L_S);          // axis x e: linear part of the motion subspace (link frame)
         M3 E; V3 r;
@@ -254,7 +255,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         }
         if (is_link) {
             float *pc = cacheL + CACHE * lane;
-            pc[26] = lk[L_MAXVEL]; pc[27] = lk[L_MAXIMP];      // motor-row limits, read in phase 4
+            pc[C_MAXVEL] = lk[L_MAXVEL]; pc[C_MAXIMP] = lk[L_MAXIMP];      // motor-row limits, read in phase 4
         }
         Sv v0;      // base velocity: world axes, at the base COM (as the state record keeps it)
         {
@@ -741,7 +742,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         if (R0.motor) {
             const float tgt = st[HG_STATE_BASE + 2 * n + lane];
             float tv = fmaf(P.kp * (tgt - q), P.inv_dt, qd) - P.kd * qd;
-            const float maxvel = cacheL[CACHE * lane + 26];
+            const float maxvel = cacheL[CACHE * lane + C_MAXVEL];
             tv = fminf(fmaxf(tv, -maxvel), maxvel);
             R0.target_err = tv - qd;
         }
@@ -988,7 +989,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
 #pragma unroll
             for (int k = 0; k < NC3; k++) AC[k] = (!DUAL && NMX + k == lane) ? 0.f : -AC[k] * dinv;
-            if (row_motor) { hi = cacheL[CACHE * lane + 27]; lo = -hi; }
+            if (row_motor) { hi = cacheL[CACHE * lane + C_MAXIMP]; lo = -hi; }
             else if (row_contact && col < MAXC) { lo = 0.f; hi = 1e10f; }
             lim_b *= dinv;          // start value of the limit row's candidate: b_l / A_ii
         }
