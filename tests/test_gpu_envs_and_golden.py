@@ -430,3 +430,23 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     assert rec["n_gpus"] == 2 and rec["config"]["envs_per_gpu"] == 256 and rec["config"]["state_finite"]
     assert rec["global_env_steps"] == 2 * 256 * (12 + 4)            # both ranks' counters arrived through the all-reduce
     assert rec["value"] > 0 and rec["per_rank_ms_per_step"]["max"] >= rec["per_rank_ms_per_step"]["min"] > 0
+
+
+def test_example_drivers_run(capsys):
+    """examples/random_control.py and examples/h5_control.py (the reference's examples/*.py on this library): single env
+    with the reference's return types, and batched."""
+    import importlib.util
+    mods = {}
+    for name in ("random_control", "h5_control"):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(HERE), "examples", name + ".py"))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    obs = mods["random_control"].main(["dancer", "--steps", "20"])
+    assert isinstance(obs, list) and len(obs) == 18                                  # dancer_env.py:52
+    obs = mods["random_control"].main(["pepper", "--envs", "64", "--steps", "20"])
+    assert tuple(obs["anglesPosition"].shape) == (64, 12)                           # pepper_env.py:64-68, batched
+    obs = mods["h5_control"].main(["nao"])
+    assert isinstance(obs, list) and len(obs) == 22 and np.isfinite(obs).all()       # nao_env.py:73
+    obs = mods["h5_control"].main(["pepper", "--envs", "8"])
+    assert np.isfinite(obs["anglesPosition"].cpu().numpy()).all()
+    assert "replayed 240 frames" in capsys.readouterr().out
