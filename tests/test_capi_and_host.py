@@ -193,3 +193,36 @@ def test_reference_robot_kernel_variants_use_no_scratch():
         r = res[variant]
         assert r["scratch_bytes_per_lane"] == 0, (robot, variant, r)
         assert r["occupancy_waves_per_simd"] == waves, (robot, variant, r)
+
+
+def test_parity_bookkeeping_helpers():
+    """The helpers the GPU parity tests lean on, exercised on the CPU: FloatParity lets a few contact samples be
+    outliers (bounded, counted) and nothing else; IntParity accepts a different contact set only with margin slack."""
+    from test_gpu_parity import FloatParity, IntParity, SLACK_TOL
+    fp = FloatParity(1e-4, 0.03)
+    for _ in range(300):
+        fp.add(4, 2e-6, 1e-3)
+    fp.add(12, 3e-3, 0.5)                    # one degenerate contact sample
+    fp.report("unit")                        # 1 <= max(1, ceil(0.004 * 301)) = 2
+    fp.add(7, 2e-3); fp.add(7, 2e-3)
+    with pytest.raises(AssertionError):
+        fp.report("unit")                    # three outliers among 303 contact samples
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(0, 2e-4)       # a contact-free sample may never be an outlier
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(3, 0.5)        # beyond the bound
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(3, float("nan"))
+
+    class _Cpu:
+        n_envs = 2
+        def __init__(self, slack): self.slack = slack
+        def contact_slack(self, e): return (self.slack[e], 1e30)
+    o = dict(n_contacts=np.array([1, 1]), pairs=np.zeros((2, 12, 2), np.int32), link_mask=np.array([2, 2], np.uint64),
+             collision=np.array([1, 1], np.uint8))
+    counts, pairs, mask = np.array([1, 2]), np.zeros((2, 12, 2), np.int32), np.array([2, 2], np.uint64)
+    ip = IntParity(); ip.pre(_Cpu([1.0, SLACK_TOL / 2]))
+    assert ip.check(0, o, counts, pairs, mask) and not ip.check(1, o, counts, pairs, mask)      # env 1 differs, explained by slack
+    ip = IntParity(); ip.pre(_Cpu([1.0, 1e-3]))
+    with pytest.raises(AssertionError):
+        ip.check(1, o, counts, pairs, mask)                                                     # differs, nothing near the margin
