@@ -225,3 +225,46 @@ def test_hands_envs_and_full_size_invariants():
     grouped = s1.view(n_envs // 16, 16, -1)
     assert bool((grouped == grouped[0:1]).all())
     sim.close()
+
+
+@pytest.mark.parametrize("robot,variant,cfg_kw", [
+    ("nao", 2, {}), ("nao", 3, dict(max_contacts=12)), ("nao", 6, dict(max_contacts=12)), ("nao", 7, {}), ("nao", 8, {}),
+    ("nao", 9, dict(max_contacts=6)), ("nao", 10, {}), ("nao", 11, {}), ("nao", 12, dict(max_contacts=12)),
+    ("pepper", 5, {}), ("pepper", 6, {}), ("pepper", 10, {}), ("dancer", 3, {}), ("dancer", 12, {}),
+])
+def test_every_kernel_instantiation_agrees_with_the_oracle(robot, variant, cfg_kw, monkeypatch):
+    """hg_sim.hip instantiates 13 shapes of the step kernel; the four robots and the two hands models pick 0, 1, 4, 7,
+    10 and 11 by themselves.  HG_VARIANT (a diagnostics override read by hg_create) forces the others -- and the
+    two-rows-per-lane shapes 10-12 onto robots that normally run one row per lane -- so that every compiled shape is
+    held to the same one-step bar."""
+    import torch
+    from humanoid_gym_amd._capi import HgSim
+    monkeypatch.setenv("HG_VARIANT", str(variant))
+    model, cfg = load_robot(robot)
+    for k, v in cfg_kw.items():
+        setattr(cfg, k, v)
+    n_envs = 6
+    gpu, cpu = HgSim(model, cfg, n_envs, "cuda:0"), OracleSim(model, cfg, n_envs)
+    monkeypatch.delenv("HG_VARIANT")
+    rng = np.random.default_rng(40 + variant)
+    idx = np.asarray(model.act_joint)
+    lo, hi = np.maximum(model.lower[idx], -1.2), np.minimum(model.upper[idx], 1.2)
+    ip, fp, contacts = IntParity(), FloatParity(2e-4), 0      # 2e-4 like the random trees: Dancer's 1e5 N m motors on the two-rows-per-lane shapes reach 1.3e-4
+    for t in range(50):
+        if t % 10 == 0:
+            act = rng.uniform(lo, hi, (n_envs, len(idx))).astype(np.float32).astype(np.float64)
+        cpu.state[:] = cpu.state.astype(np.float32)
+        gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+        ip.pre(cpu)
+        o = cpu.step(act)
+        gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
+        pairs, counts, mask = gpu.contact_pairs()
+        pairs, counts, mask = pairs.cpu().numpy(), counts.cpu().numpy(), mask.cpu().numpy().astype(np.uint64)
+        contacts += int(o["n_contacts"].sum())
+        for e in range(n_envs):
+            if ip.check(e, o, counts, pairs, mask):
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()))
+    ip.report(f"{robot} on variant {variant}")
+    fp.report(f"{robot} on variant {variant}")
+    assert contacts > 0
+    gpu.close()
