@@ -156,6 +156,16 @@ def _dbg(msg):
         print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
+    stdout when the box exports NCCL_DEBUG=VERSION), so from here on file descriptor 1 of this process is stderr, and the
+    file object returned -- the real stdout -- is used for the JSON line only."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +185,7 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+    json_out = claim_stdout()
     if os.environ.get("HG_BENCH_DEBUG"):     # where does a stuck rank sit?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["HG_BENCH_DEBUG"]), exit=True)
@@ -284,7 +295,8 @@ def main():
                               "vs_baseline": None, "dtype": "none", "data": "none", "backend": args.backend,
                               "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms)},
                               "global_env_steps": global_env_steps,
-                              "config": {"workload": "dry", "envs_per_gpu": n_envs, "first_env_of_rank0": first_env}}))
+                              "config": {"workload": "dry", "envs_per_gpu": n_envs, "first_env_of_rank0": first_env}}),
+                  file=json_out, flush=True)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -414,7 +426,7 @@ def main():
             out["nao_with_finger_joints"] = with_hands
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
