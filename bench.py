@@ -14,7 +14,7 @@ One "step" = one hg_step launch over all envs of this rank (targets -> physics
 -> observations, with the per-env episode-statistics accumulation fused into the
 kernel's output stage); actions are resident in HBM before the timed region.  N > 1: one process per GPU,
 envs sharded with no data-path collective; the only collective is hg_stats_flush + the RCCL all-reduce of
-the 8-float episode-statistics vector every 32 steps on a side stream.  `python bench.py --gpus N` with no
+the 8-float episode-statistics vector every 64 steps on a side stream.  `python bench.py --gpus N` with no
 RANK in the environment starts the N ranks itself (a child `python -m torch.distributed.run`, the parent
 never touches a GPU) and relays rank 0's line; under an outer torchrun it is one of the ranks.
 
