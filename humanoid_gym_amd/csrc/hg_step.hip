@@ -978,7 +978,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
         float z, lo = 0.f, hi = 0.f;
         {
-            const float dinv = (row_active && diag > 1e-20f) ? __frcp_rn(diag) : 0.f;
+            const float dinv = (row_active && diag > (float)HG_ROW_DEN_EPS) ? __frcp_rn(diag) : 0.f;      // else: row disabled (hg_model.h)
             z = target_err * dinv;
 #pragma unroll
             for (int k = 0; k < NMX; k++) {
@@ -1174,7 +1174,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // joint's motor lane, see the one-row-per-lane solver above for the algebra).
         float z1, lo1 = 0.f, hi1 = 0.f;
         {
-            const float dinvB = (R1.contact && diagB > 1e-20f) ? __frcp_rn(diagB) : 0.f;
+            const float dinvB = (R1.contact && diagB > (float)HG_ROW_DEN_EPS) ? __frcp_rn(diagB) : 0.f;
             z1 = R1.target_err * dinvB;
 #pragma unroll
             for (int k = 0; k < NMX; k++) {

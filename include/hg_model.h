@@ -33,6 +33,17 @@ extern "C" {
 #define HG_MAX_PAIRS    1024 /* self-collision sphere pairs                        */
 #define HG_MAX_CONTACTS 12   /* contact slots per env per physics step             */
 #define HG_MAX_ROWS     128  /* n_links + 3*max_contacts: one row per lane up to 64, two per lane beyond   */
+/* A constraint row whose denominator J M^-1 J^T is not above this is DISABLED (impulse 0), as
+ * btMultiBodyConstraint::fillMultiBodyConstraint does with SIMD_EPSILON ("disable the constraint row to handle
+ * singularity/redundant constraint") [UPSTREAM-RECALL].  Such rows exist: two collision spheres centred on the
+ * joint axes of two root children overlap for ever and no coordinate of the robot moves one against the other
+ * (J = 0 identically).  What the arithmetic then sees is rounding noise of J: ~1e-13 / kg in FP32, ~1e-30 in FP64.
+ * The value is FLT_EPSILON -- Bullet's single-precision SIMD_EPSILON, 8e6 kg of effective mass -- for the FP32
+ * kernel AND the FP64 oracle, so that both disable the same rows (a double-precision Bullet uses DBL_EPSILON; no
+ * row of a real robot lies between the two). */
+#ifndef HG_ROW_DEN_EPS
+#define HG_ROW_DEN_EPS  1.1920929e-7
+#endif
 
 typedef struct hg_model {
     int32_t n_links;                       /* n: moving links / dofs                */

@@ -473,6 +473,10 @@ typedef struct {
     int normal_row;     /* for friction rows: index of the normal row, else -1 */
 } row_t;
 
+/* 1 / (J M^-1 J^T), or 0 = row disabled when the denominator vanishes (HG_ROW_DEN_EPS, hg_model.h): rhs and every
+ * update of such a row are 0, its impulse stays 0 */
+static double row_diag_inv(double den) { return den > HG_ROW_DEN_EPS ? 1.0 / den : 0.0; }
+
 static void resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int ndof) {
     double lo = r->lo, hi = r->hi;
     if (r->normal_row >= 0) {
@@ -554,7 +558,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         r->J[6 + i] = lim_sign[k];
         impulse_response(m, &W, r->J, r->u);
         HGO_FLOPS(8);
-        r->diag_inv = 1.0 / (lim_sign[k] * r->u[6 + i]);
+        r->diag_inv = row_diag_inv(lim_sign[k] * r->u[6 + i]);
         r->rhs = (-lim_pen[k] * c->contact_erp / dt - lim_sign[k] * qd[i]) * r->diag_inv;
         r->lo = 0; r->hi = c->limit_max_impulse; r->lambda = 0; r->normal_row = -1;
     }
@@ -568,7 +572,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         if (target > m->max_vel[i]) target = m->max_vel[i];
         if (target < -m->max_vel[i]) target = -m->max_vel[i];
         impulse_response(m, &W, r->J, r->u);
-        r->diag_inv = 1.0 / r->u[6 + i];
+        r->diag_inv = row_diag_inv(r->u[6 + i]);
         r->rhs = (target - qd[i]) * r->diag_inv;
         r->lo = -m->max_force[i] * dt; r->hi = m->max_force[i] * dt;
         r->lambda = 0; r->normal_row = -1;
@@ -583,7 +587,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         double den = 0, rv = 0;
         HGO_FLOPS(4 * ndof + 6);
         for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
-        r->diag_inv = 1.0 / den;
+        r->diag_inv = row_diag_inv(den);
         double pos_err = 0, vel_err = -rv;
         if (con[k].dist > 0) vel_err -= con[k].dist / dt;
         else pos_err = -con[k].dist * c->contact_erp / dt;
@@ -603,7 +607,7 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
             double den = 0, rv = 0;
             HGO_FLOPS(4 * ndof + 2);
             for (int j = 0; j < ndof; j++) { den += r->J[j] * r->u[j]; rv += r->J[j] * vel[j]; }
-            r->diag_inv = 1.0 / den;
+            r->diag_inv = row_diag_inv(den);
             r->rhs = -rv * r->diag_inv;
             r->lo = 0; r->hi = 0; r->lambda = 0; r->normal_row = first_normal + k;
         }

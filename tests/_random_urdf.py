@@ -66,3 +66,23 @@ def write_random_tree(path, **kw):
     with open(path, "w") as f:
         f.write(text)
     return path, made
+
+
+def degenerate_pair_urdf():
+    """Two children of the base whose collision boxes are centred on their joint pivots and overlap: the inscribed
+    spheres touch for ever and NO coordinate of the robot moves one centre against the other -- a contact row whose
+    Jacobian vanishes identically (found by tools/fuzz_trees.py; see HG_ROW_DEN_EPS in include/hg_model.h)."""
+    def link(name, m, box):
+        return (f'<link name="{name}"><inertial><origin xyz="0.004 -0.003 0.01" rpy="0.1 0.2 0.3"/><mass value="{m}"/>'
+                f'<inertia ixx="3e-4" ixy="0" ixz="0" iyy="4e-4" iyz="0" izz="5e-4"/></inertial>'
+                f'<collision><geometry><box size="{box} {box} {box}"/></geometry></collision></link>')
+
+    def joint(name, parent, child, xyz, axis):
+        return (f'<joint name="{name}" type="revolute"><parent link="{parent}"/><child link="{child}"/><origin xyz="{xyz}" rpy="0.2 -0.1 0"/>'
+                f'<axis xyz="{axis}"/><limit lower="-2.0" upper="2.0" effort="5.0" velocity="20"/></joint>')
+
+    return "\n".join(['<robot name="degenerate_pair">', link("base", 0.5, 0.08),
+                      link("left", 0.3, 0.04), link("right", 0.25, 0.04), link("left_tip", 0.1, 0.03), link("right_tip", 0.1, 0.03),
+                      joint("j_left", "base", "left", "0.012 0 -0.05", "0.6 0 0.8"), joint("j_right", "base", "right", "-0.012 0 -0.05", "0 0.8 0.6"),
+                      joint("j_left_tip", "left", "left_tip", "0.03 0.05 -0.06", "1 0 0"), joint("j_right_tip", "right", "right_tip", "-0.03 0.05 -0.06", "0 1 0"),
+                      "</robot>"])

@@ -14,12 +14,50 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_tree_shapes_slice():
     import fuzz_trees
     r = fuzz_trees.run(n_cases=40, seed=11)
-    assert r["cases"] >= 30 and r["contact_samples"] > 1000
-    assert r["outliers"] <= 2
+    assert r.cases >= 30 and r.contact_samples > 1000
+    assert r.outliers <= 2 and len(r.ill) <= 3
 
 
 def test_robots_under_random_world_parameters_slice():
     import fuzz_robots
     r = fuzz_robots.run(n_cases=40, seed=11)
-    assert r["cases"] == 40 and r["contact_samples"] > 2000
-    assert r["outliers"] <= 2 and r["ill_conditioned"] <= 3
+    assert r.cases == 40 and r.contact_samples > 2000
+    assert r.outliers <= 2 and len(r.ill) <= 3
+
+
+def test_vanishing_contact_row(tmp_path):
+    """The degenerate configuration the tree fuzzer found (tests/_random_urdf.py degenerate_pair_urdf): a contact row
+    whose Jacobian vanishes identically must be disabled by the kernel as by the oracle -- before HG_ROW_DEN_EPS the
+    kernel divided by FP32 rounding noise (1e-13) and flung the robot to the velocity clamp in one step."""
+    import numpy as np
+    import torch
+    from _random_urdf import degenerate_pair_urdf
+    from _oracle import OracleSim
+    from humanoid_gym_amd._capi import HgSim
+    from humanoid_gym_amd.model import SimConfig
+    from humanoid_gym_amd.urdf import load_urdf
+    p = tmp_path / "deg.urdf"
+    p.write_text(degenerate_pair_urdf())
+    model = load_urdf(str(p), base_position=(0, 0, 0.12), self_collision=True, name="deg")
+    n, n_envs = model.n_links, 4
+    rng = np.random.default_rng(3)
+    for over in (dict(max_contacts=4), dict(max_contacts=8, solver_iters=7), dict(max_contacts=12, friction=0.0)):
+        cfg = SimConfig()
+        cfg.enable_self, cfg.enable_ground = True, False      # (ground contacts come first in the list and would take the slots)
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        gpu, cpu = HgSim(model, cfg, n_envs, "cuda:0"), OracleSim(model, cfg, n_envs)
+        saw = 0
+        for t in range(60):
+            if t % 15 == 0:
+                act = rng.uniform(-1, 1, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
+            cpu.state[:] = cpu.state.astype(np.float32)
+            gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
+            o = cpu.step(act)
+            gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
+            st = gpu.get_state().cpu().numpy()
+            saw += int(sum([0, 2] in o["pairs"][e][:o["n_contacts"][e]].tolist() for e in range(n_envs)))
+            assert np.abs(gq - o["q"]).max() < 1e-4, (over, t)
+            assert np.abs(st[:, 13 + n:13 + 2 * n] - cpu.qd).max() < 2e-2, (over, t)
+        assert saw > 100, saw          # the overlapping pair is there nearly all the time
+        gpu.close()

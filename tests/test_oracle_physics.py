@@ -260,3 +260,23 @@ def test_counted_flops_agree_with_the_roofline_formula():
         formula = bench.algorithmic_flops_per_env_step(model, cfg, n_contacts=r["mean_contacts"], n_substeps=sub)
         assert r["flops_per_env_step"] > 0
         assert abs(formula / r["flops_per_env_step"] - 1.0) < 0.2, (name, r, formula)
+
+
+def test_vanishing_contact_row_is_disabled(tmp_path):
+    """Two spheres centred on the joint pivots of two root children overlap for ever: no coordinate moves one centre
+    against the other, the row's denominator J M^-1 J^T is rounding noise, and the row is disabled (HG_ROW_DEN_EPS,
+    include/hg_model.h; Bullet: "disable the constraint row to handle singularity/redundant constraint").  Without
+    the guard the row's impulse runs to its 1e10 cap and 1e10 x noise is what the robot gets."""
+    from _random_urdf import degenerate_pair_urdf
+    from humanoid_gym_amd.urdf import load_urdf
+    p = tmp_path / "deg.urdf"
+    p.write_text(degenerate_pair_urdf())
+    model = load_urdf(str(p), base_position=(0, 0, 0.5), self_collision=True, name="deg")
+    model.max_force = np.zeros(model.n_links)
+    cfg = SimConfig()
+    cfg.enable_self, cfg.enable_ground, cfg.max_contacts, cfg.gravity = True, False, 4, (0.0, 0.0, 0.0)
+    sim = OracleSim(model, cfg, 1)
+    for t in range(5):
+        o = sim.step(None)
+        assert o["n_contacts"][0] == 1 and o["pairs"][0][0].tolist() == [0, 2]
+    assert np.abs(sim.qd).max() == 0.0 and np.abs(sim.state[0, 7:13]).max() == 0.0
