@@ -5,14 +5,14 @@ classified.  The bars are those of the GPU tests (tests/test_gpu_parity.py: IntP
 Sample classes that are NOT compared (each counted in the summary; FUZZ_STRICT=1 compares the second and third too):
   clamp   a velocity coordinate beyond 90 % of the clamp (or of 100 rad/s when the clamp is off) before or after the step,
           or a diverged oracle: the clamp is a discontinuity and a runaway env loses 1e-4 rad to the rounding of q alone;
-  dup     several contacts between one pair of links: singular Delassus matrix, the split between the duplicates is
+  dup     several contacts between one pair of links (in any substep of the step): singular Delassus matrix, the split between the duplicates is
           decided by rounding (profiles/round2_d_one_step_outliers.txt);
   tie     (several substeps, limit rows on) a joint closer to a bound than the position tolerance at the start of a later
           substep: it rests on the bound under its limit row, leaves a substep at bound +- rounding noise, and whether the
           next substep builds the row again is a coin toss in any arithmetic.
 Samples that ARE compared and miss a bar (joint angles beyond the tolerance; with several substeps also a contact set that
 differs without a candidate at the margin -- the last substep starts from states the two sides reached by their own
-arithmetic) are put to the oracle itself: +-1 ulp (FP32) on its input, 4 trials.  If its own FP64 answer moves by more
+arithmetic) are put to the oracle itself: 4 trials with +-1 ulp (FP32) on its input state, 4 with 1e-6 relative noise.  If its own FP64 answer moves by more
 than tolerance / 20, an FP32 step -- hundreds of roundings inside -- cannot be held to the tolerance: logged as
 ill-conditioned with both numbers.  Otherwise the sample counts (FloatParity's outlier allowance) or fails the run.
 With ONE substep the contact set comes from the shared state and a difference the margin slack does not explain fails at once."""
@@ -45,7 +45,7 @@ class Totals:
 
     def print_ill(self):
         for rec in self.ill:
-            print("  ill-conditioned: %s, %d contacts: kernel - oracle %.3g rad%s, oracle under +-1 ulp %.3g rad" % rec)
+            print("  ill-conditioned: %s, %d contacts: kernel - oracle %.3g rad%s, oracle under input noise %.3g rad" % rec)
 
 
 def _ulp_nudge(x64, rng):
@@ -75,6 +75,18 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
         g2.close()
         return o2, q2
 
+    def dump_sample(sub_dir, e, before, o, gq):
+        dump = os.environ.get("FUZZ_DUMP")
+        if dump:        # the sample, for tools/fuzz_replay.py
+            import dataclasses, json, shutil
+            dump = os.path.join(dump, sub_dir)
+            os.makedirs(dump, exist_ok=True)
+            np.savez(os.path.join(dump, "sample.npz"), before=before, act=act, sel=np.asarray([] if sel is None else sel, np.int32), sub=sub, env=e,
+                     kernel_q=gq, oracle_q=o["q"])
+            json.dump(dict(tag=tag, cfg=dataclasses.asdict(cfg), has_sel=sel is not None, urdf=urdf is not None, name=model.name), open(os.path.join(dump, "sample.json"), "w"))
+            if urdf:
+                shutil.copy(urdf, os.path.join(dump, "sample.urdf"))
+
     def fail(e, t, why, before, o, gq):
         print("FAILED", tag, f"step {t} env {e}: {why}")
         dq = np.abs(gq[e] - o["q"][e])
@@ -84,15 +96,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
         for s2 in range(1, sub + 1):
             o2, q2 = both(before, s2)
             print(f"  the same sample with {s2} substep(s): max |dq| {np.abs(q2[e] - o2['q'][e]).max():.3g}")
-        dump = os.environ.get("FUZZ_DUMP")
-        if dump:        # the failing sample, for tools/fuzz_replay.py
-            import dataclasses, json, shutil
-            os.makedirs(dump, exist_ok=True)
-            np.savez(os.path.join(dump, "sample.npz"), before=before, act=act, sel=np.asarray([] if sel is None else sel, np.int32), sub=sub, env=e,
-                     kernel_q=gq, oracle_q=o["q"])
-            json.dump(dict(tag=tag, cfg=dataclasses.asdict(cfg), has_sel=sel is not None, urdf=urdf is not None, name=model.name), open(os.path.join(dump, "sample.json"), "w"))
-            if urdf:
-                shutil.copy(urdf, os.path.join(dump, "sample.urdf"))
+        dump_sample("", e, before, o, gq)
         raise AssertionError("fuzz failure (details printed above): " + tag)
 
     for t in range(N_STEPS):
@@ -104,8 +108,12 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
         skip = fast(before)
         tie = np.zeros(N_ENVS, bool)
         walk.state[:] = before
+        dup = np.zeros(N_ENVS, bool)
         for s2 in range(sub - 1):
-            walk.step(act if s2 == 0 else None, joint_sel=sel if s2 == 0 else None, n_substeps=1)
+            ow = walk.step(act if s2 == 0 else None, joint_sel=sel if s2 == 0 else None, n_substeps=1)
+            for e in range(N_ENVS):       # the duplicate-pair class counts in EVERY substep, not only in the reported one
+                ll = [(int(a), int(b)) for a, b in ow["pairs"][e][:int(ow["n_contacts"][e])] if b >= 0]
+                dup[e] |= len(ll) != len(set(ll))
             if cfg.enable_limits and len(lim_idx):
                 d = np.minimum(np.abs(walk.q - model.lower), np.abs(walk.q - model.upper))
                 tie |= (d[:, lim_idx] < tol).any(1)
@@ -121,7 +129,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
             ll = [(int(a), int(b)) for a, b in o["pairs"][e][:nce] if b >= 0]
             if skip[e]:
                 tot.clamp += 1; continue
-            if len(ll) != len(set(ll)) and not STRICT:
+            if (dup[e] or len(ll) != len(set(ll))) and not STRICT:
                 tot.dup += 1; continue
             if tie[e] and not STRICT:
                 tot.tie += 1; continue
@@ -135,9 +143,9 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
             dq_e = float(np.abs(gq[e] - o["q"][e]).max())
             if int_why is not None or (identical and not dq_e < tol):
                 sens = 0.0
-                for trial in range(4):
+                for trial in range(8):      # 4 x +-1 ulp, then 4 x 1e-6 relative (~16 ulp: roundings INSIDE an FP32 step add up to that)
                     walk.state[:] = before
-                    walk.state[e] = _ulp_nudge(before[e], rng)
+                    walk.state[e] = _ulp_nudge(before[e], rng) if trial < 4 else before[e] * (1.0 + 1e-6 * rng.normal(size=before.shape[1]))
                     sens = max(sens, float(np.abs(walk.step(act, joint_sel=sel, n_substeps=sub)["q"][e] - o["q"][e]).max()))
                 if sens > tol / 20:
                     if int_why is not None:
@@ -147,10 +155,13 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                 if int_why is not None:
                     fail(e, t, int_why + f" (oracle under +-1 ulp: {sens:.3g} rad)", before, o, gq)
             if identical:
+                n_out = len(fp.outliers)
                 try:
                     fp.add(nce, dq_e)
                 except AssertionError as err:
                     fail(e, t, str(err), before, o, gq)
+                if len(fp.outliers) > n_out:
+                    dump_sample(f"outlier_{tag.split(':')[0].replace(' ', '')}_{t}_{e}", e, before, o, gq)
         if blown.any():
             break
     try:
