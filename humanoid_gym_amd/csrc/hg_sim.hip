@@ -282,8 +282,42 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
 static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
+// Numbers the step divides by, takes square roots of or indexes with: checked once here, because a NaN mass or a zero
+// inertia does not fault -- it makes every env of the handle "non-finite" and the guard resets it on every step, silently.
+static int check_numbers(const hg_model *m, const hg_config *c, std::string *why) {
+    auto fin = [](const double *v, int k) { for (int i = 0; i < k; i++) if (!std::isfinite(v[i])) return false; return true; };
+    auto pos = [](const double *v, int k) { for (int i = 0; i < k; i++) if (!(v[i] > 0) || !std::isfinite(v[i])) return false; return true; };
+    auto bad = [&](const char *what, int i) { *why = std::string(what) + (i >= 0 ? " (index " + std::to_string(i) + ")" : ""); return HG_EINVAL; };
+    if (!pos(&m->base_mass, 1) || !pos(m->base_inertia, 3)) return bad("base mass and principal inertia must be positive and finite", -1);
+    if (!fin(m->base_pos0, 3) || !fin(m->base_quat0, 4)) return bad("base reset pose must be finite", -1);
+    {
+        const double *q = m->base_quat0;
+        if (std::fabs(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] - 1.0) > 1e-3) return bad("base reset quaternion must be a unit quaternion", -1);
+    }
+    for (int i = 0; i < m->n_links; i++) {
+        if (!pos(&m->mass[i], 1) || !pos(m->inertia[i], 3)) return bad("link mass and principal inertia must be positive and finite", i);
+        if (!fin(m->R0[i], 9) || !fin(m->d[i], 3) || !fin(m->e[i], 3) || !fin(&m->q_init[i], 1)) return bad("link frame constants must be finite", i);
+        const double *a = m->axis[i];
+        if (!fin(a, 3) || std::fabs(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] - 1.0) > 1e-3) return bad("joint axis must be a unit vector", i);
+        if (!(m->joint_damping[i] >= 0) || !std::isfinite(m->joint_damping[i])) return bad("joint damping must be finite and >= 0", i);
+        if (!(m->max_force[i] >= 0) || !(m->max_vel[i] >= 0)) return bad("motor force and velocity bounds must be >= 0 (may be infinite)", i);
+        if (std::isnan(m->lower[i]) || std::isnan(m->upper[i]) || m->lower[i] > m->upper[i]) return bad("joint bounds must satisfy lower <= upper", i);
+    }
+    for (int b = 0; b <= m->n_links; b++)
+        if (!fin(m->frame_pos[b], 3) || !fin(m->frame_quat[b], 4)) return bad("URDF frame offsets must be finite", b);
+    for (int s = 0; s < m->n_spheres; s++)
+        if (!fin(m->sphere_pos[s], 3) || !(m->sphere_radius[s] >= 0) || !std::isfinite(m->sphere_radius[s])) return bad("collision sphere centre / radius must be finite, radius >= 0", s);
+    if (!fin(c->gravity, 3) || !(c->kp >= 0) || !(c->kd >= 0) || !(c->contact_erp >= 0) || !(c->friction >= 0) || !(c->lin_damping >= 0) ||
+        !(c->ang_damping >= 0) || !(c->limit_max_impulse >= 0) || !std::isfinite(c->contact_margin) || std::isnan(c->max_coord_velocity) ||
+        !std::isfinite(c->kp) || !std::isfinite(c->kd) || !std::isfinite(c->contact_erp) || !std::isfinite(c->friction) ||
+        !std::isfinite(c->lin_damping) || !std::isfinite(c->ang_damping) || !std::isfinite(c->dt))
+        return bad("config: gravity, gains, erp, friction, damping and limit_max_impulse must be finite and >= 0", -1);
+    return HG_OK;
+}
+
 static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, std::string *why) {
     const int n = m->n_links;
+    if (int rc = check_numbers(m, c, why)) return rc;
     memset(D, 0, sizeof(DevModel));
     D->n = n; D->n_spheres = m->n_spheres; D->n_pairs = m->n_pairs; D->n_act = m->n_act;
     int nchild[HG_MAX_LINKS] = {0}, last_child[HG_MAX_LINKS];
@@ -413,6 +447,7 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         if (m->pair_a[k] < 0 || m->pair_a[k] >= m->n_spheres || m->pair_b[k] < 0 || m->pair_b[k] >= m->n_spheres) {
             *why = "self-collision pair out of range"; return HG_EINVAL;
         }
+        if (m->sphere_link[m->pair_a[k]] == m->sphere_link[m->pair_b[k]]) { *why = "self-collision pair within one body"; return HG_EINVAL; }
         self_of[m->pair_a[k]] = self_of[m->pair_b[k]] = 0;
     }
     for (int s = 0; s < m->n_spheres; s++)

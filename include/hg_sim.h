@@ -53,6 +53,11 @@ int hg_abi_version(void);
  * setPhysicsEngineParameter + setTimeStep  (dancer_env.py:13,58-65) and
  * SimulationManager.launchSimulation + spawnNao/spawnPepper/spawnRomeo
  * (nao_env.py:17-20, pepper_env.py:15-18, romeo_env.py:14-17).
+ * The model and config are checked on the host before a device is looked for: HG_EINVAL for sizes / indices out of
+ * range, links not ordered parents-first, masses or principal inertias that are not positive and finite, a joint axis
+ * or reset quaternion that is not of unit length, lower > upper, negative or NaN gains / bounds, a self-collision pair
+ * inside one body; HG_EUNSUPPORTED for trees no kernel instantiation fits (depth > 12, forks nested deeper than 2,
+ * rows beyond HG_MAX_ROWS).  hg_last_error() names the offending field and index.
  */
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out);
 

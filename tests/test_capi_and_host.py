@@ -226,3 +226,55 @@ def test_parity_bookkeeping_helpers():
     ip = IntParity(); ip.pre(_Cpu([1.0, 1e-3]))
     with pytest.raises(AssertionError):
         ip.check(1, o, counts, pairs, mask)                                                     # differs, nothing near the margin
+
+
+def test_hg_create_rejects_numbers_the_step_cannot_use():
+    """A NaN mass or a zero inertia does not fault on the device: every env of the handle turns non-finite and the guard
+    resets it on every step, silently.  hg_create checks the numbers on the host (before it looks for a device)."""
+    import math
+    L = _capi.load_library()
+    h = C.c_void_p()
+    for name in ("dancer", "nao", "pepper", "romeo", "nao_hands", "romeo_hands"):      # the shipped models pass the checks
+        m, cfg = load_robot(name)
+        cm, cc = m.to_c(), cfg.to_c()
+        rc = L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h))
+        assert rc in (0, -2), (name, rc, L.hg_last_error())
+        if rc == 0:
+            L.hg_destroy(h)
+    m, cfg = load_robot("nao")
+
+    def rejected(edit_model=None, edit_cfg=None):
+        cm, cc = m.to_c(), cfg.to_c()
+        if edit_model:
+            edit_model(cm)
+        if edit_cfg:
+            edit_cfg(cc)
+        rc = L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h))
+        assert rc == -1 and h.value is None, (rc, L.hg_last_error())
+        return L.hg_last_error()
+
+    def put(field, i, v, k=None):
+        def edit(cm):
+            if i is None:
+                setattr(cm, field, v)
+            elif k is None:
+                getattr(cm, field)[i] = v
+            else:
+                getattr(cm, field)[i][k] = v
+        return edit
+
+    assert b"link mass" in rejected(put("mass", 3, float("nan")))
+    assert b"link mass" in rejected(put("mass", 0, 0.0))
+    assert b"(index 5)" in rejected(put("inertia", 5, -1e-4, 1))
+    assert b"base mass" in rejected(put("base_mass", None, math.inf))
+    assert b"unit vector" in rejected(lambda cm: [cm.axis[2].__setitem__(k, 0.0) for k in range(3)])
+    assert b"unit quaternion" in rejected(put("base_quat0", 3, 2.0))
+    assert b"lower <= upper" in rejected(lambda cm: (cm.lower.__setitem__(1, 1.0), cm.upper.__setitem__(1, -1.0)))
+    assert b"bounds must be >= 0" in rejected(put("max_force", 4, -1.0))
+    assert b"sphere" in rejected(put("sphere_radius", 0, float("nan")))
+    assert b"frame constants" in rejected(put("d", 7, float("inf"), 2))
+    assert b"config" in rejected(edit_cfg=lambda cc: setattr(cc, "friction", float("nan")))
+    assert b"config" in rejected(edit_cfg=lambda cc: cc.gravity.__setitem__(2, float("inf")))
+    assert b"config" in rejected(edit_cfg=lambda cc: setattr(cc, "kp", -0.1))
+    if len(m.pair_a):
+        assert b"within one body" in rejected(lambda cm: cm.pair_b.__setitem__(0, cm.pair_a[0]))
