@@ -389,7 +389,7 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure is the one
         # of the committed rocprofv3 --pmc passes over this same kernel and configuration (named in traffic_source)
         traffic, traffic_source = None, None
-        for cand in ("round2_e_pmc_nao4096.json", "round2_c_pmc_nao4096.json", "round2_pmc_nao4096.json", "round1_g_pmc_nao4096.json"):
+        for cand in ("round2_f_pmc_nao4096.json", "round2_e_pmc_nao4096.json", "round2_c_pmc_nao4096.json", "round2_pmc_nao4096.json", "round1_g_pmc_nao4096.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if args.robot == "nao" and n_envs == 4096 and not args.cfg:
