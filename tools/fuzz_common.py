@@ -2,6 +2,12 @@
 count, stepped 40 times on the kernel (through the C-ABI) and the oracle from shared FP32 states, every (env, step) sample
 classified.  The bars are those of the GPU tests (tests/test_gpu_parity.py: IntParity, FloatParity).
 
+Compared per sample: contact count, link pairs, link mask and collision flag (integers, IntParity); observed joint angles,
+base x / y / yaw (yaw scaled by the horizontal length of the heading axis), joint rates and applied motor torques (FloatParity).
+Every fourth step: getLinkState poses of the kernel's own post-step state against the oracle's forward kinematics of that
+state (3e-5 m / 3e-5 in the quaternion); at step 20: hg_reset under a random mask.  A case may carry a base velocity command
+(hg_set_base_velocity, Pepper).
+
 Sample classes that are NOT compared (each counted in the summary; FUZZ_STRICT=1 compares the second and third too):
   clamp   a velocity coordinate beyond 90 % of the clamp (or of 100 rad/s when the clamp is off) before or after the step,
           or a diverged oracle: the clamp is a discontinuity and a runaway env loses 1e-4 rad to the rounding of q alone;
@@ -12,8 +18,8 @@ Sample classes that are NOT compared (each counted in the summary; FUZZ_STRICT=1
           next substep builds the row again is a coin toss in any arithmetic.
 Samples that ARE compared and miss a bar (joint angles beyond the tolerance; with several substeps also a contact set that
 differs without a candidate at the margin -- the last substep starts from states the two sides reached by their own
-arithmetic) are put to the oracle itself: 4 trials with +-1 ulp (FP32) on its input state, 4 with 1e-6 relative noise.  If its own FP64 answer moves by more
-than tolerance / 20, an FP32 step -- hundreds of roundings inside -- cannot be held to the tolerance: logged as
+arithmetic) are put to the oracle itself: 4 trials with +-1 ulp (FP32) on its input state, 4 with 1e-6 relative noise.  If its own FP64 answer (angles, rates or torques, each against
+its tolerance) moves by more than tolerance / 20, an FP32 step -- hundreds of roundings inside -- cannot be held to the tolerance: logged as
 ill-conditioned with both numbers.  Otherwise the sample counts (FloatParity's outlier allowance) or fails the run.
 With ONE substep the contact set comes from the shared state and a difference the margin slack does not explain fails at once."""
 import os
@@ -35,17 +41,27 @@ N_ENVS, N_STEPS = 5, 40
 class Totals:
     def __init__(self):
         self.cases = self.samples = self.contact_samples = self.outliers = 0
-        self.clamp = self.dup = self.tie = 0
+        self.clamp = self.dup = self.tie = self.fk = 0
         self.ill = []
 
     def line(self):
         return (f"{self.cases} cases stepped ({self.samples} samples compared, {self.contact_samples} of them with contacts, "
                 f"{self.outliers} counted outliers, {len(self.ill)} ill-conditioned; not compared: {self.clamp} at the velocity clamp or "
-                f"diverged, {self.dup} with duplicate link-link contacts, {self.tie} with a joint at a bound between substeps)")
+                f"diverged, {self.dup} with duplicate link-link contacts, {self.tie} with a joint at a bound between substeps; "
+                f"link poses of {self.fk} states equal to the oracle's forward kinematics)")
 
     def print_ill(self):
         for rec in self.ill:
-            print("  ill-conditioned: %s, %d contacts: kernel - oracle %.3g rad%s, oracle under input noise %.3g rad" % rec)
+            print("  ill-conditioned: %s, %d contacts: kernel - oracle %s%s; oracle under input noise %s" % rec)
+
+
+def _heading_length(qb, qf):
+    """hypot(R00, R10) of R(qb) R(qf), quaternions xyzw"""
+    x1, y1, z1, w1 = qb
+    x2, y2, z2, w2 = qf
+    x, y, z, w = (w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                  w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2)
+    return float(np.hypot(1 - 2 * (y * y + z * z), 2 * (x * y + z * w)))
 
 
 def _ulp_nudge(x64, rng):
@@ -54,14 +70,19 @@ def _ulp_nudge(x64, rng):
     return np.where(b32 != 0, moved, b32)
 
 
-def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None):
+def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None):
     """Steps one case; raises AssertionError (after printing what it knows) on a failure."""
     n = model.n_links
     gpu = HgSim(model, cfg, N_ENVS, "cuda:0")
+    if base_cmd is not None:      # commanded planar base velocity (hg_set_base_velocity: sticky until released)
+        base_cmd = np.asarray(base_cmd, np.float32).astype(np.float64)
+        gpu.set_base_velocity(torch.tensor(base_cmd, dtype=torch.float32))
     cpu, walk = OracleSim(model, cfg, N_ENVS), OracleSim(model, cfg, N_ENVS)
+    fresh = cpu.state.copy()
     cpu.state[:, 7:13] = rng.uniform(-base_vel, base_vel, (N_ENVS, 6))
     # several substeps: the slack is taken at the oracle's state before the LAST one, against 1e-4 rad of drift on a 0.5 m lever
-    ip, fp = IntParity(2e-6 if sub == 1 else 5e-5), FloatParity(tol)
+    ip = IntParity(2e-6 if sub == 1 else 5e-5)
+    fp = FloatParity(tol, 300 * tol, 50 * tol)      # q [rad]; qd [rad/s] (q error = dt * qd error); motor torque relative to max(1, largest torque)
     lim_idx = np.flatnonzero(model.limited)
     vlim = 0.9 * (min(cfg.max_coord_velocity, 100.0) if cfg.max_coord_velocity > 0 else 100.0)
     fast = lambda st: (np.abs(st[:, 7:13]).max(1) > vlim) | (np.abs(st[:, 13 + n:13 + 2 * n]).max(1) > vlim)
@@ -69,8 +90,10 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     def both(state, n_sub):
         walk.state[:] = state
         g2 = HgSim(model, cfg, N_ENVS, "cuda:0")
+        if base_cmd is not None:
+            g2.set_base_velocity(torch.tensor(base_cmd, dtype=torch.float32))
         g2.set_state(torch.tensor(state, dtype=torch.float32))
-        o2 = walk.step(act, joint_sel=sel, n_substeps=n_sub)
+        o2 = walk.step(act, joint_sel=sel, n_substeps=n_sub, base_cmd=base_cmd)
         q2 = g2.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel, n_substeps=n_sub)[0].cpu().numpy()
         g2.close()
         return o2, q2
@@ -102,6 +125,13 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     for t in range(N_STEPS):
         if t % 10 == 0:
             act = rng.uniform(act_lo, act_hi, (N_ENVS, n_cols)).astype(np.float32).astype(np.float64)
+        if t == 20:      # hg_reset under a random mask: masked envs at the reset state, the others untouched
+            m = rng.random(N_ENVS) < 0.5
+            prev = gpu.get_state().cpu().numpy()
+            gpu.reset(torch.tensor(m))
+            now = gpu.get_state().cpu().numpy()
+            assert np.array_equal(now[~m], prev[~m]), f"FAILED {tag}: hg_reset touched an env outside its mask"
+            assert np.abs(now[m] - fresh[m]).max(initial=0.0) < 1e-6, f"FAILED {tag}: hg_reset state differs from the oracle's reset state"
         cpu.state[:] = cpu.state.astype(np.float32)
         before = cpu.state.copy()
         gpu.set_state(torch.tensor(before, dtype=torch.float32))
@@ -110,7 +140,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
         walk.state[:] = before
         dup = np.zeros(N_ENVS, bool)
         for s2 in range(sub - 1):
-            ow = walk.step(act if s2 == 0 else None, joint_sel=sel if s2 == 0 else None, n_substeps=1)
+            ow = walk.step(act if s2 == 0 else None, joint_sel=sel if s2 == 0 else None, n_substeps=1, base_cmd=base_cmd)
             for e in range(N_ENVS):       # the duplicate-pair class counts in EVERY substep, not only in the reported one
                 ll = [(int(a), int(b)) for a, b in ow["pairs"][e][:int(ow["n_contacts"][e])] if b >= 0]
                 dup[e] |= len(ll) != len(set(ll))
@@ -118,10 +148,12 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                 d = np.minimum(np.abs(walk.q - model.lower), np.abs(walk.q - model.upper))
                 tie |= (d[:, lim_idx] < tol).any(1)
         ip.pre(walk)
-        o = cpu.step(act, joint_sel=sel, n_substeps=sub)
+        o = cpu.step(act, joint_sel=sel, n_substeps=sub, base_cmd=base_cmd)
         gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel, n_substeps=sub)[0].cpu().numpy()
         pairs, counts, mask = gpu.contact_pairs()
         pairs, counts, mask = pairs.cpu().numpy(), counts.cpu().numpy(), mask.cpu().numpy().astype(np.uint64)
+        g_qd, g_col, g_xy = gpu.obs_qd.cpu().numpy(), gpu.collision.cpu().numpy(), gpu.base_xyyaw.cpu().numpy()
+        g_tau = gpu.joint_torques().cpu().numpy()
         blown = ~np.isfinite(cpu.state).all(1) | (np.abs(np.nan_to_num(cpu.state, nan=1e30)).max(1) > 1e6)      # e.g. ONE sweep on a 62-link tree
         skip |= blown | fast(np.nan_to_num(cpu.state, nan=1e30))
         for e in range(N_ENVS):
@@ -135,33 +167,63 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                 tot.tie += 1; continue
             int_why = None
             try:
-                identical = ip.check(e, o, counts, pairs, mask)
+                identical = ip.check(e, o, counts, pairs, mask, g_col)
             except AssertionError as err:
                 identical, int_why = False, str(err)
                 if sub == 1:
                     fail(e, t, int_why, before, o, gq)
-            dq_e = float(np.abs(gq[e] - o["q"][e]).max())
-            if int_why is not None or (identical and not dq_e < tol):
-                sens = 0.0
+            # the compared floats, each against its own tolerance: (joint angles + base x, y, yaw), joint rates, motor torques
+            def measure(q_obs, qd_obs, xy, tau, quat):
+                dxy = xy - o["base_xyyaw"][e]
+                # yaw = atan2(R10, R00) of the base LINK frame: scaled by the horizontal length of that frame's x axis (a base
+                # lying on its nose has no heading; the raw angle is then decided by rounding)
+                dxy[2] = ((dxy[2] + np.pi) % (2 * np.pi) - np.pi) * _heading_length(quat, model.frame_quat[0])
+                return (max(float(np.abs(q_obs - o["q"][e]).max()), float(np.abs(dxy).max())), float(np.abs(qd_obs - o["qd"][e]).max()),
+                        float(np.abs(tau - o["motor_torque"][e]).max()) / max(1.0, float(np.abs(o["motor_torque"][e]).max())))
+            vals = measure(gq[e], g_qd[e], g_xy[e], g_tau[e], cpu.state[e, 3:7])
+            dq_e = vals[0]
+            if int_why is not None or (identical and any(not v < tl for v, tl in zip(vals, fp.tol))):
+                sens, worst = 0.0, (0.0, 0.0, 0.0)      # largest move of the oracle's own answer, in units of the tolerances
                 for trial in range(8):      # 4 x +-1 ulp, then 4 x 1e-6 relative (~16 ulp: roundings INSIDE an FP32 step add up to that)
                     walk.state[:] = before
                     walk.state[e] = _ulp_nudge(before[e], rng) if trial < 4 else before[e] * (1.0 + 1e-6 * rng.normal(size=before.shape[1]))
-                    sens = max(sens, float(np.abs(walk.step(act, joint_sel=sel, n_substeps=sub)["q"][e] - o["q"][e]).max()))
-                if sens > tol / 20:
+                    o2 = walk.step(act, joint_sel=sel, n_substeps=sub, base_cmd=base_cmd)
+                    v2 = measure(o2["q"][e], o2["qd"][e], o2["base_xyyaw"][e], o2["motor_torque"][e], walk.state[e, 3:7])
+                    if max(v / tl for v, tl in zip(v2, fp.tol)) > sens:
+                        sens, worst = max(v / tl for v, tl in zip(v2, fp.tol)), v2
+                if sens > 1 / 20:
                     if int_why is not None:
                         ip.total -= 1
-                    tot.ill.append((tag.split(":")[0], nce, dq_e, " and another contact set" if int_why else "", sens))
+                    tot.ill.append((tag.split(":")[0], nce, "%.3g rad, %.3g rad/s, torque %.3g" % vals, " and another contact set" if int_why else "",
+                                    "%.3g rad, %.3g rad/s, torque %.3g" % worst))
                     continue
                 if int_why is not None:
-                    fail(e, t, int_why + f" (oracle under +-1 ulp: {sens:.3g} rad)", before, o, gq)
+                    fail(e, t, int_why + f" (oracle under input noise: {sens:.3g} of the tolerance)", before, o, gq)
             if identical:
                 n_out = len(fp.outliers)
                 try:
-                    fp.add(nce, dq_e)
+                    fp.add(nce, *vals)
                 except AssertionError as err:
                     fail(e, t, str(err), before, o, gq)
                 if len(fp.outliers) > n_out:
+                    print(f"  outlier: {tag.split(':')[0]} step {t} env {e}, {nce} contacts: %.3g rad, %.3g rad/s, torque %.3g (relative)" % vals)
                     dump_sample(f"outlier_{tag.split(':')[0].replace(' ', '')}_{t}_{e}", e, before, o, gq)
+        if t % 4 == 0:
+            # getLinkState: the kernel's link poses from the kernel's OWN post-step state against the oracle's forward
+            # kinematics of that same state (a pure function of the state, so every env counts, whatever its sample class)
+            st = gpu.get_state().cpu().numpy().astype(np.float64)
+            ok = np.isfinite(st).all(1) & (np.abs(st[:, :3]).max(1) < 50.0)
+            walk.state[:] = np.where(ok[:, None], st, before)
+            got = [x.cpu().numpy() for x in gpu.link_states()]
+            want = walk.link_states()
+            for e in np.flatnonzero(ok):
+                for k in (0, 2):
+                    err = np.abs(got[k][e] - want[k][e]).max()
+                    assert err < 3e-5, f"FAILED {tag} step {t} env {e}: link {'COM' if k == 0 else 'frame'} positions differ by {err:.3g} m"
+                for k in (1, 3):
+                    err = np.minimum(np.abs(got[k][e] - want[k][e]).max(1), np.abs(got[k][e] + want[k][e]).max(1)).max()
+                    assert err < 3e-5, f"FAILED {tag} step {t} env {e}: link {'COM' if k == 1 else 'frame'} orientations differ by {err:.3g}"
+            tot.fk += int(ok.sum())
         if blown.any():
             break
     try:

@@ -38,7 +38,10 @@ def run(n_cases=60, seed=1):
         lo, hi = np.maximum(model.lower[idx], -1.5) - 0.2, np.minimum(model.upper[idx], 1.5) + 0.2      # a little beyond the bounds: clamp_targets, limit rows
         # a step of k substeps of length dt accumulates k * dt * (velocity error): the 1e-4 rad of the one-substep, 1/240 s tests, scaled
         tol = max(2e-4, 1e-4 * sub * over["dt"] * 240)
-        run_case(tot, f"case {case}: {robot} {over} substeps {sub} columns {len(idx)}", model, cfg, sub, rng, lo, hi, len(idx), sel=sel, tol=tol)
+        cmd = None
+        if robot == "pepper" and rng.random() < 0.6:      # the base driven like qibullet's PepperBaseController (hg_set_base_velocity)
+            cmd = np.column_stack([rng.uniform(-0.5, 0.5, (5, 2)), rng.uniform(-1.0, 1.0, 5)])
+        run_case(tot, f"case {case}: {robot} {over} substeps {sub} columns {len(idx)}" + (" base command" if cmd is not None else ""), model, cfg, sub, rng, lo, hi, len(idx), sel=sel, tol=tol, base_cmd=cmd)
     print("fuzz robots:", tot.line() + "; no failure")
     tot.print_ill()
     return tot
