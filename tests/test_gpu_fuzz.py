@@ -61,3 +61,20 @@ def test_vanishing_contact_row(tmp_path):
             assert np.abs(st[:, 13 + n:13 + 2 * n] - cpu.qd).max() < 2e-2, (over, t)
         assert saw > 100, saw          # the overlapping pair is there nearly all the time
         gpu.close()
+
+
+def test_launch_shapes_slice():
+    """Whole launches of 1, 65 and 4097 envs (one env, a partial wave round, one env beyond a resident round), every env
+    against the oracle (tools/fuzz_batch.py; its long runs: profiles/round2_f_fuzz_batch.txt)."""
+    import numpy as np
+    from fuzz_common import Totals, run_case
+    from humanoid_gym_amd.robots import load_robot
+    rng = np.random.default_rng(5)
+    tot = Totals()
+    for n_envs in (1, 65, 4097):
+        model, cfg = load_robot("nao")
+        model.lower, model.upper = model.lower.astype(np.float32).astype(np.float64), model.upper.astype(np.float32).astype(np.float64)
+        idx = np.asarray(model.act_joint)
+        lo, hi = np.maximum(model.lower[idx], -1.5), np.minimum(model.upper[idx], 1.5)
+        run_case(tot, f"case {n_envs}: nao x {n_envs} envs", model, cfg, 1, rng, lo, hi, len(idx), tol=2e-4, n_envs=n_envs, n_steps=6)
+    assert tot.cases == 3 and tot.samples > 20000 and tot.outliers <= 3

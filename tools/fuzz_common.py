@@ -6,7 +6,7 @@ Compared per sample: contact count, link pairs, link mask and collision flag (in
 base x / y / yaw (yaw scaled by the horizontal length of the heading axis), joint rates and applied motor torques (FloatParity).
 Every fourth step: getLinkState poses of the kernel's own post-step state against the oracle's forward kinematics of that
 state (3e-5 m / 3e-5 in the quaternion); at step 20: hg_reset under a random mask.  A case may carry a base velocity command
-(hg_set_base_velocity, Pepper).
+(hg_set_base_velocity, Pepper); fuzz_batch.py runs the same over whole launches of 1 .. 40 000 envs.
 
 Sample classes that are NOT compared (each counted in the summary; FUZZ_STRICT=1 compares the second and third too):
   clamp   a velocity coordinate beyond 90 % of the clamp (or of 100 rad/s when the clamp is off) before or after the step,
@@ -70,9 +70,11 @@ def _ulp_nudge(x64, rng):
     return np.where(b32 != 0, moved, b32)
 
 
-def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None):
+def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None, n_envs=None, n_steps=None):
     """Steps one case; raises AssertionError (after printing what it knows) on a failure."""
     n = model.n_links
+    N_ENVS = n_envs or globals()["N_ENVS"]
+    N_STEPS = n_steps or globals()["N_STEPS"]
     gpu = HgSim(model, cfg, N_ENVS, "cuda:0")
     if base_cmd is not None:      # commanded planar base velocity (hg_set_base_velocity: sticky until released)
         base_cmd = np.asarray(base_cmd, np.float32).astype(np.float64)
@@ -125,7 +127,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     for t in range(N_STEPS):
         if t % 10 == 0:
             act = rng.uniform(act_lo, act_hi, (N_ENVS, n_cols)).astype(np.float32).astype(np.float64)
-        if t == 20:      # hg_reset under a random mask: masked envs at the reset state, the others untouched
+        if t == N_STEPS // 2:      # hg_reset under a random mask: masked envs at the reset state, the others untouched
             m = rng.random(N_ENVS) < 0.5
             prev = gpu.get_state().cpu().numpy()
             gpu.reset(torch.tensor(m))
