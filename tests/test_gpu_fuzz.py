@@ -78,3 +78,15 @@ def test_launch_shapes_slice():
         lo, hi = np.maximum(model.lower[idx], -1.5), np.minimum(model.upper[idx], 1.5)
         run_case(tot, f"case {n_envs}: nao x {n_envs} envs", model, cfg, 1, rng, lo, hi, len(idx), tol=2e-4, n_envs=n_envs, n_steps=6)
     assert tot.cases == 3 and tot.samples > 20000 and tot.outliers <= 3
+
+
+def test_closed_loop_statistics_match_the_oracle():
+    """Free-running rollouts separate trajectory by trajectory (contacts: chaos), so the closed-loop check is statistical:
+    512 NAO envs x 240 steps on both sides with the same targets -- mean base height, joint-rate rms, collision rate and
+    contact count stay together and the final heights are one distribution (tools/rollout_stats.py; four robots at 1024 x
+    480 in profiles/round2_f_rollout_stats.txt).  A systematic bias of the FP32 kernel would show here."""
+    import rollout_stats
+    r = rollout_stats.rollout("nao", 512, 240)
+    assert r["finite"] and r["ks_p"] > 1e-3, r
+    assert r["height"]["worst_abs"] < 0.01 and r["collision"]["worst_abs"] < 0.05 and r["contacts"]["worst_abs"] < 0.4, r
+    assert r["qd_rms"]["worst_rel"] < 0.15, r
