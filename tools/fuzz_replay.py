@@ -19,6 +19,9 @@ if meta["urdf"]:
 else:
     model, _ = load_robot(meta["name"])
     model.lower, model.upper = model.lower.astype(np.float32).astype(np.float64), model.upper.astype(np.float32).astype(np.float64)
+if "max_force" in z.files:
+    model.max_force, model.max_vel = z["max_force"], z["max_vel"]
+base_cmd = z["base_cmd"] if "base_cmd" in z.files and len(z["base_cmd"]) else None
 n = model.n_links
 print(meta["tag"], "env", e)
 qb = before[e, 13:13 + n]
@@ -33,8 +36,10 @@ def run(label, **over):
         setattr(cfg, k, v)
     g, c = HgSim(model, cfg, before.shape[0], "cuda:0"), OracleSim(model, cfg, before.shape[0])
     c.state[:] = before
+    if base_cmd is not None:
+        g.set_base_velocity(torch.tensor(base_cmd, dtype=torch.float32))
     g.set_state(torch.tensor(before, dtype=torch.float32))
-    o = c.step(act, joint_sel=sel, n_substeps=n_sub)
+    o = c.step(act, joint_sel=sel, n_substeps=n_sub, base_cmd=base_cmd)
     out = g.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel, n_substeps=n_sub)
     q = out[0].cpu().numpy()
     st = g.get_state().cpu().numpy()
@@ -42,8 +47,11 @@ def run(label, **over):
     dq = np.abs(q[e] - o["q"][e])
     dqd = np.abs(st[e, 13 + n:13 + 2 * n] - c.qd[e])
     bad = np.nonzero(dqd > 1e-2)[0]
+    dtau = np.abs(tau[e] - o["motor_torque"][e])
+    jt = int(dtau.argmax())
     print(f"{label:44s} max |dq| {dq.max():.3g} (column {dq.argmax()}), max |dqd| {dqd.max():.3g}; links with |dqd| > 1e-2: {bad.tolist()}; "
-          f"contacts {int(o['n_contacts'][e])}")
+          f"contacts {int(o['n_contacts'][e])}; torque: link {jt} kernel {tau[e][jt]:.6g} oracle {o['motor_torque'][e][jt]:.6g} "
+          f"(bound {model.max_force[jt]:.3g}, q {st[e, 13 + jt]:.5f} in [{model.lower[jt]:.5f}, {model.upper[jt]:.5f}])")
     g.close()
     return o, st
 

@@ -1,7 +1,8 @@
 """Differential fuzzing of the step kernel against the oracle on the six robot models under random WORLD parameters:
 contact slots 1..12 (which also moves a model onto other kernel shapes), 1 / 7 / 50 / 51 / 150 solver sweeps, 1..4
 substeps, time step, gravity direction, motor gains, erp, friction, damping, velocity clamp, every enable flag, random
-joint subsets as action columns, targets a little beyond the joint bounds.  Sample classes and bars: fuzz_common.py.
+joint subsets as action columns, targets a little beyond the joint bounds; in 40 % of the cases motor force / velocity
+bounds that bind, limit rows that saturate and another manifold margin.  Sample classes and bars: fuzz_common.py.
 The joint bounds are rounded to FP32 for both sides: a joint that clamp_targets parks exactly ON float32(bound) is "at the
 bound" for the device and 6e-9 rad inside it for an oracle that holds the FP64 bound.
 usage (GPU box): python tools/fuzz_robots.py [n_cases] [seed]"""
@@ -27,6 +28,10 @@ def run(n_cases=60, seed=1):
                     friction=float(rng.uniform(0.0, 1.2)), lin_damping=float(rng.uniform(0, 0.1)), ang_damping=float(rng.uniform(0, 0.1)),
                     max_coord_velocity=float(rng.choice([100.0, 30.0, 0.0])), enable_ground=bool(rng.random() < 0.85),
                     enable_self=bool(rng.random() < 0.6), clamp_targets=bool(rng.random() < 0.7), enable_limits=bool(rng.random() < 0.7))
+        if rng.random() < 0.4:      # motor bounds that bind: weak motors, slow motors; limit rows that saturate; another manifold margin
+            over.update(limit_max_impulse=float(10.0 ** rng.uniform(-4, 2)), contact_margin=float(rng.choice([0.002, 0.005, 0.02, 0.05])))
+            model.max_force = model.max_force * 10.0 ** rng.uniform(-3, 1, model.n_links)
+            model.max_vel = np.where(rng.random(model.n_links) < 0.5, rng.uniform(0.2, 3.0, model.n_links), model.max_vel)
         for k, v in over.items():
             setattr(cfg, k, v)
         sub = int(rng.integers(1, 5))
