@@ -1238,7 +1238,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     }
             }
         };
-        auto limit_update = [&](const int i) {             // i: wave-uniform, known at run time
+        // The finger-joint models rest most of their fingers ON a bound (q = 0 = lower): 2 (NAO) to 7 (Romeo) limit rows per
+        // env and sweep are the common case here.  Measured on one box (tools/hands_limits_ab.py; HEAD = indexed reads only):
+        //   61-dof Romeo, 7.2 such rows per env: indexed reads 1.368 ms per step, scan 1.231 ms, compare tree into the per-joint code 1.372 ms
+        //   42-dof NAO,   2.0 such rows per env: indexed reads 0.374 ms,          scan 0.427 ms
+        // "scan" walks ALL joints with compile-time indices and a scalar test of each joint's mask bit (columns in named
+        // registers, one-lane writes under an immediate EXEC); "indexed reads" loops over the set bits and fetches the joint's
+        // column with an indexed register read.  Same rows, same order either way: scan beyond 48 joints, indexed reads up to 48.
+        auto limit_update_at = [&](const int i) {          // compile-time i
+            const float zl = fmaf(lim_s, z - lamv0, lam_l + lim_k);
+            const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), i));
+            z = fmaf(colA(i), d, z);                        // a_ii = 0: lane i is handled below
+            z1 = fmaf(colB(i), d, z1);
+            asm volatile("s_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, %5\n\tv_mov_b32 %0, %2\n\tv_subrev_f32 %1, %3, %1\n\ts_mov_b64 exec, -1"
+                         : "+v"(lam_l), "+v"(z) : "v"(cand), "s"(d), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
+        };
+        auto limit_update_idx = [&](const int i) __attribute__((always_inline)) {   // i: wave-uniform, known at run time
             const float zl = lam_l + lim_k + lim_s * (z - lamv0);
             const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
             const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), i));
@@ -1252,20 +1268,39 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             z1 = fmaf(b_i, d, z1);
             if (lane == i) { lam_l = cand; z -= d; }
         };
+        static_assert(NMX <= 64, "limit mask");
+        constexpr bool LIM_SCAN = NMX > 48;
+        const unsigned lim_lo32 = (unsigned)limmask, lim_hi32 = (unsigned)(limmask >> 32);
         auto sweep2 = [&](const bool forward) {
             if (forward) {
-                #pragma unroll 1
-                for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update(__builtin_ctzll(mk));
+                if constexpr (LIM_SCAN) {
+                    if (limmask != 0ull) {
+#pragma unroll
+                        for (int i = 0; i < NMX; ++i)
+                            if (((i < 32 ? lim_lo32 : lim_hi32) >> (i & 31)) & 1u) limit_update_at(i);
+                    }
+                } else {
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update_idx(__builtin_ctzll(mk));
+                }
 #pragma unroll
                 for (int i = 0; i < NMX; ++i) motor_update(i);
             } else {
 #pragma unroll
                 for (int i = NMX - 1; i >= 0; --i) motor_update(i);
-                #pragma unroll 1
-                for (unsigned long long mk = limmask; mk != 0ull;) {
-                    const int i = 63 - __builtin_clzll(mk);
-                    limit_update(i);
-                    mk &= ~(1ull << i);
+                if constexpr (LIM_SCAN) {
+                    if (limmask != 0ull) {
+#pragma unroll
+                        for (int i = NMX - 1; i >= 0; --i)
+                            if (((i < 32 ? lim_lo32 : lim_hi32) >> (i & 31)) & 1u) limit_update_at(i);
+                    }
+                } else {
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull;) {
+                        const int i = 63 - __builtin_clzll(mk);
+                        limit_update_idx(i);
+                        mk &= ~(1ull << i);
+                    }
                 }
             }
             contact_rows();
