@@ -1438,11 +1438,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     const int lane = fresh_lane();
     const bool is_link = lane < n;
     // ---- non-finite guard: reset the env in place and raise done ---------------------------------
-    float q = 0.f, qd = 0.f;
-    if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; }
+    float q = 0.f, qd = 0.f, tgt = 0.f;
+    if (is_link) { q = st[HG_STATE_BASE + lane]; qd = st[HG_STATE_BASE + n + lane]; tgt = st[HG_STATE_BASE + 2 * n + lane]; }
     V3 bpos = ld3(st);
     float bq[4] = {st[3], st[4], st[5], st[6]};
-    bool bad = !(isfinite(q) && isfinite(qd));
+    // (the stored motor target counts: an infinite action is clamped into a finite target velocity and would otherwise stay
+    // in the record for ever without making anything else non-finite)
+    bool bad = !(isfinite(q) && isfinite(qd) && isfinite(tgt));
     {
         const V3 bvel = ld3(st + 7), bang = ld3(st + 10);
         bad = bad || !(isfinite(bpos.x + bpos.y + bpos.z + bvel.x + bvel.y + bvel.z + bang.x + bang.y + bang.z + bq[0] + bq[1] + bq[2] + bq[3]));
