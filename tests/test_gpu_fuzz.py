@@ -92,7 +92,7 @@ def test_closed_loop_statistics_match_the_oracle():
     assert r["qd_rms"]["worst_rel"] < 0.15, r
 
 
-@pytest.mark.parametrize("robot", ["nao", "dancer", "romeo_hands"])
+@pytest.mark.parametrize("robot", ["nao", "dancer", "pepper", "romeo", "nao_hands", "romeo_hands"])
 def test_garbage_states_and_actions_neither_fault_nor_leak(robot):
     """hg_set_state / actions with anything in them -- NaN, infinities, 1e30, a zero quaternion, angles of 1e4 rad, a base
     1e6 m away: the step must not fault, every env must be finite afterwards (the guard resets what turned non-finite, `done`
