@@ -1,6 +1,6 @@
 """Differential fuzzing of the step kernel against the oracle over random articulated trees and configs: tree size 1..62,
 depth up to 12, 1..6 chains, nested side chains, 0..12 contact slots, link-link contacts on / off, joint limits on / off,
-odd / even solver sweep counts, 1..3 substeps (random boxes of sibling links often overlap at rest, so the duplicate-pair
+odd / even solver sweep counts, 1..3 substeps, in 30 % of the shapes link masses scaled by 0.01 .. 10 each (random boxes of sibling links often overlap at rest, so the duplicate-pair
 class of fuzz_common.py is common here).  Sample classes and bars: fuzz_common.py.  Shapes the library refuses
 (HG_EUNSUPPORTED / HG_EINVAL from hg_create) are counted, not failed.
 usage (GPU box): python tools/fuzz_trees.py [n_cases] [seed]"""
@@ -36,6 +36,9 @@ def run(n_cases=60, seed=1):
             model = load_urdf(path, base_position=(0, 0, float(rng.uniform(0.05, 0.3))), self_collision=self_on, name="tree")
         except Exception as e:          # the generator cannot build this shape (e.g. too shallow for the link count)
             print(tag, "-> generator:", str(e)[:80]); refused += 1; continue
+        if rng.random() < 0.3:          # mass ratios of up to 1000 between neighbouring links (the generator draws 0.05 .. 0.4 kg)
+            k = 10.0 ** rng.uniform(-2, 1, model.n_links)
+            model.mass, model.inertia = model.mass * k, model.inertia * k[:, None]
         cfg = SimConfig()
         for k, v in over.items():
             setattr(cfg, k, v)
