@@ -32,16 +32,23 @@ import bench
 from humanoid_gym_amd import _capi
 from humanoid_gym_amd.robots import load_robot
 
+import ast
 robot = sys.argv[1] if len(sys.argv) > 1 else "nao"
 n_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+overrides = dict(a.split("=", 1) for a in sys.argv[3:])      # SimConfig overrides, e.g. max_contacts=6
 L = _capi.load_library(LIB)
 _capi._lib = L
 L.hg_debug_phase_ticks.restype = C.c_int
 L.hg_debug_phase_ticks.argtypes = [C.c_void_p, C.c_int]
 dev = torch.device("cuda", 0)
 model, cfg = load_robot(robot)
-if robot == "nao":
+for k, v in overrides.items():
+    setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
+if robot in ("nao", "nao_hands"):          # the bench workload: h5-layout replay (+ the fingers' mimic columns)
     rows, sel = bench.synthetic_replay(model)
+    if robot == "nao_hands":
+        from humanoid_gym_amd.workloads import nao_replay_joints
+        rows, sel = bench.with_mimic_columns(model, rows, sel, nao_replay_joints())
 else:
     sel = np.asarray(model.act_joint, np.int32)
     rows = np.random.default_rng(2).uniform(model.lower[sel], model.upper[sel], (bench.T_TRAJ, len(sel))).astype(np.float32)
@@ -53,6 +60,12 @@ acts = torch.stack([rows_d[(t + phase) % T] for t in range(T)]).contiguous()
 for t in range(60):
     sim.step(acts[t % T], joint_sel=sel)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for t in range(60, 100):
+    sim.step(acts[t % T], joint_sel=sel)
+e1.record(); torch.cuda.synchronize()
+print(f"{robot} {n_envs} envs {overrides}: {e0.elapsed_time(e1) / 40:.4f} ms per step (diagnostics build), variant {os.environ.get('HG_VARIANT', 'auto')}")
 ne = min(n_envs, 4096)
 buf = np.zeros((ne, 16), np.uint64)
 assert L.hg_debug_phase_ticks(buf.ctypes.data_as(C.c_void_p), ne) == 16
