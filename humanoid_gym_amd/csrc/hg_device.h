@@ -105,8 +105,15 @@ __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 // registers: DEPTH * WAVE floats laid over an array that is dead by then (the sphere distances).  For the shapes whose A-rows leave no registers for them: 12 contact slots (hipcc
 // spilled them to scratch) and two rows per lane (NAO + fingers 6 % faster, Romeo + hands 4.5 %).  Measured on the
 // others too: NAO and Pepper within 1 %, Romeo 10 % slower (the extra 1.3 KB of LDS costs it a wave per SIMD).
+// Rows beyond the 64 lanes of a wave.  Up to HG_MAX_OVF of them (the friction pairs of the LAST contact slots) are
+// "overflow rows": they have no lane; their candidate impulse is formed from a wave reduction once per sweep (hg_step.hip,
+// 4b "overflow rows").  More rows than that: two rows per lane (DUAL).
+#define HG_MAX_OVF 2
+__host__ __device__ constexpr int ovf_rows(int nmx, int maxc) {
+    return (nmx + 3 * maxc > 64 && nmx + 3 * maxc - 64 <= HG_MAX_OVF && (nmx + 3 * maxc) % 2 == 0) ? nmx + 3 * maxc - 64 : 0;
+}
 #ifndef HG_YS_LDS
-#define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 || (nmx) + 3 * (maxc) > 64)
+#define HG_YS_LDS(nmx, maxc, depth) ((maxc) >= 12 || ((nmx) + 3 * (maxc) > 64 && ovf_rows(nmx, maxc) == 0))
 #endif
 __host__ __device__ constexpr int ys_floats(int nmx, int maxc, int depth) { return HG_YS_LDS(nmx, maxc, depth) ? depth * WAVE : 0; }
 __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, int n_self, int nrows, int ys, int cstride) {

@@ -16,7 +16,10 @@
 #include "../../include/hg_sim.h"
 #include "hg_device.h"
 #include "hg_math.h"
-#include "hg_step.hip"
+#include "hg_variants.h"
+#ifndef HG_SPLIT_TU
+#include "hg_step_launch.h"      // single translation unit: the step kernel and its launchers are compiled here
+#endif
 
 namespace hg {
 
@@ -262,25 +265,6 @@ struct hg_sim {
 
 namespace hg {
 
-// kernel instantiations: motor lanes, contact slots, tree depth, branch slots, waves per SIMD
-struct Variant { int nmx, maxc, depth, nsl, wpe; };
-#define HG_VARIANTS(X) \
-    X(0, 18, 12, 6, 0, 4)  /* dancer (scratch-free at 4 waves/SIMD since round 2; 3 waves/SIMD is 18 % slower) */ \
-    X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
-    X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
-    X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
-    X(4, 20, 8, 9, 2, 4)   /* pepper (deep chain, branching torso)     */ \
-    X(5, 20, 8, 12, 2, 4)  /* 20 dofs, deeper chains                   */ \
-    X(6, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
-    X(7, 37, 8, 12, 2, 3)  /* romeo: 61 rows, 3 lanes left for limits  */ \
-    X(8, 40, 8, 12, 2, 3)  /* up to 40 dofs                            */ \
-    X(9, 46, 6, 12, 2, 3)  /* anything up to 46 dofs, 6 contacts       */ \
-    X(10, 44, 8, 12, 2, 2) /* nao with finger joints (42 dofs): 68 rows, two rows per lane */ \
-    X(11, 62, 8, 12, 2, 2) /* romeo with hands, anything up to 62 dofs: 86 rows (1 wave/SIMD = no scratch, but 1.5x slower) */ \
-    X(12, 62, 12, 12, 2, 2) /* catch-all: every model within the limits of hg_model.h has a kernel */
-#define HG_VARIANT_ROW(i, a, b, c, d, e) {a, b, c, d, e},
-static const Variant kVariants[] = {HG_VARIANTS(HG_VARIANT_ROW)};
-constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 // Numbers the step divides by, takes square roots of or indexes with: checked once here, because a NaN mass or a zero
 // inertia does not fault -- it makes every env of the handle "non-finite" and the guard resets it on every step, silently.
@@ -462,13 +446,6 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
     return HG_OK;
 }
 
-template <int NMX, int MAXC, int DEPTH, int NSL, int WPE>
-static hipError_t launch_step(const hg_sim *s, const StepParams &P, const float *actions, const StepOut &O, hipStream_t st) {
-    hipLaunchKernelGGL((hg_step_kernel<NMX, MAXC, DEPTH, NSL, WPE>), dim3(s->n_envs), dim3(WAVE), s->lds_bytes, st,
-                       s->d_model, P, s->d_state, actions, O);
-    return hipGetLastError();
-}
-
 }  // namespace hg
 
 using namespace hg;
@@ -482,12 +459,16 @@ const char *hg_last_error(void) { return g_err.c_str(); }
 int hg_abi_version(void) { return 5; }
 
 #ifdef HG_PHASE_TIMING
-// diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch
+// diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch (of the variant launched last)
+static int g_last_variant = -1;
 extern "C" int hg_debug_phase_ticks(unsigned long long *host_out, int n_envs) {
     if (n_envs > HG_TICK_ENVS) n_envs = HG_TICK_ENVS;
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hg::hg_ticks), sizeof(unsigned long long) * HG_TICK_SLOTS * (size_t)n_envs) != hipSuccess) return -1;
-    return HG_TICK_SLOTS;
+    switch (g_last_variant) {
+#define HG_TICKS_CASE(i, a, b, c, d, w) case i: return read_ticks_v<i>(host_out, n_envs);
+        HG_VARIANTS(HG_TICKS_CASE)
+        default: return -1;
+    }
 }
 #endif
 
@@ -640,8 +621,11 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
     HG_DEVICE(s);
     hipError_t e;
     hipStream_t st = (hipStream_t)stream;
+#ifdef HG_PHASE_TIMING
+    g_last_variant = s->variant;
+#endif
     switch (s->variant) {
-#define HG_VARIANT_CASE(i, a, b, c, d, w) case i: e = launch_step<a, b, c, d, w>(s, P, actions_dev, O, st); break;
+#define HG_VARIANT_CASE(i, a, b, c, d, w) case i: e = launch_step_v<i>(s->n_envs, s->lds_bytes, st, s->d_model, P, s->d_state, actions_dev, O); break;
         HG_VARIANTS(HG_VARIANT_CASE)
         default: return fail(HG_EUNSUPPORTED, "hg_step: bad kernel variant");
     }

@@ -33,6 +33,7 @@
 // Scheduling: one wave per workgroup (a workgroup of several envs keeps its LDS until its slowest wave ends:
 // measured slower); launches that fit the GPU at once reverse the SIMD arbiter's service order of their
 // waves at solver entry with s_setprio (see 4b), so that the waves of a SIMD finish together.
+#pragma once
 #include "hg_device.h"
 #include "hg_math.h"
 
@@ -43,7 +44,7 @@ namespace hg {
 #ifdef HG_PHASE_TIMING
 #define HG_TICK_ENVS 4096
 #define HG_TICK_SLOTS 16
-__device__ unsigned long long hg_ticks[HG_TICK_ENVS][HG_TICK_SLOTS];
+static __device__ unsigned long long hg_ticks[HG_TICK_ENVS][HG_TICK_SLOTS];
 #define HG_TICK(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if (threadIdx.x == 0 && blockIdx.x < HG_TICK_ENVS) hg_ticks[blockIdx.x][K] = t_; } while (0)
 // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) in slot 13, XCC_ID in slot 14
@@ -87,6 +88,12 @@ HG_FI void wave_sync() {
 #define HG_Y_CASE(K) case K + 1: if constexpr (K < DEPTH) { Y = on_path ? Ys[K < YSN ? K : 0] : 0.f; } break;
 #define HG_Y_CASES HG_Y_CASE(0) HG_Y_CASE(1) HG_Y_CASE(2) HG_Y_CASE(3) HG_Y_CASE(4) HG_Y_CASE(5) \
                    HG_Y_CASE(6) HG_Y_CASE(7) HG_Y_CASE(8) HG_Y_CASE(9) HG_Y_CASE(10) HG_Y_CASE(11)
+
+// compile-time loop: f(IC<I>{}) for I = B .. E-1
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, typename F> HG_FI void static_for(F &&f) {
+    if constexpr (B < E) { f(IC<B>{}); static_for<B + 1, E>(f); }
+}
 
 // register vector of N floats (N <= 16): lets a wave-uniform run-time index address a VGPR directly
 template <int N> struct RegVec { typedef float type __attribute__((ext_vector_type(N))); };
@@ -623,67 +630,68 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // 85): every lane carries TWO rows, row set 0 = the motor row of joint `lane`, row set 1 = contact row `lane`
         // (lanes < NC3).  Both sets run the same row set-up and impulse-response code below; the solver keeps both
         // candidates per lane and every row update touches both.
-        constexpr bool DUAL = NROWS > WAVE;
+        // More rows than lanes by at most HG_MAX_OVF (OVF: the 42-dof NAO with 8 contact slots has 66 rows): ONE row per lane as
+        // above, motor rows on lanes < NMX, contact rows 0 .. NCL-1 on lanes NMX .. 63; the last NOV contact rows -- the friction
+        // pair of the last contact slot, live only when every slot is taken -- have no lane.  Their Jacobians are built by lanes
+        // < NOV (row set 1, as in DUAL), their mutual entries of A by a response along their own paths only (4a'), and in
+        // the sweep their candidate impulses come from a wave reduction (4b, "overflow rows").
+        constexpr int NOV = ovf_rows(NMX, MAXC);
+        constexpr bool DUAL = NROWS > WAVE && NOV == 0;
+        constexpr int NCL = NC3 - NOV;             // contact rows that have a lane
+        constexpr int OC0 = MAXC - NOV / 2;        // first contact slot whose friction pair overflows
         constexpr int CB = DUAL ? 0 : NMX;         // lane of contact column 0 (in row set 1 when DUAL)
         constexpr int CBL = DUAL ? WAVE : NMX;     // index of contact impulse 0 in lamL
-        RowVars R0, R1;                             // R1 is dead code unless DUAL
+        RowVars R0, R1;                             // R1 is dead code unless DUAL or OVF
         R0.clear(); R1.clear();
         RowVars &RC = *(DUAL ? &R1 : &R0);          // the set that carries the contact rows
-        RC.col = (lane >= CB && lane < CB + NC3) ? lane - CB : -1;          // contact-row column
-        const int cidx = RC.col < 0 ? -1 : (RC.col < MAXC ? RC.col : (RC.col - MAXC) >> 1);
-        RC.contact = cidx >= 0 && cidx < nc;
+        RC.col = (lane >= CB && lane < CB + NCL) ? lane - CB : -1;          // contact-row column
+        if constexpr (NOV > 0) R1.col = lane < NOV ? NCL + lane : -1;
+        const bool ovf_on = NOV > 0 && nc > OC0;                            // wave-uniform
         R0.motor = is_link;                              // NMX >= n by construction
         if (R0.motor) R0.body = lane;
         unsigned long long rowmask = 0ull;       // links with a non-zero row in Jc (wave-uniform)
-        if (nc > 0) {
-            const int col = RC.col;
+        // One contact row: Jacobian column into Jc (joint part on the path(s) from the contact bodies to the base, base part),
+        // desired change of J.v
+        auto contact_setup = [&](RowVars &R) __attribute__((always_inline)) {
+            const int col = R.col;
+            const int cidx = col < 0 ? -1 : (col < MAXC ? col : (col - MAXC) >> 1);
+            R.contact = cidx >= 0 && cidx < nc;
             V3 pt = v3(0, 0, 0), dir = v3(0, 0, 0);
             float dist = 0.f;
-            if (RC.contact) {
+            if (R.contact) {
                 const float *co = conL + CON * cidx;
-                RC.body = __float_as_int(co[0]);
-                RC.body2 = __float_as_int(co[1]);
+                R.body = __float_as_int(co[0]);
+                R.body2 = __float_as_int(co[1]);
                 pt = ld3(co + 2);
                 const V3 nrm = ld3(co + 5);
                 dist = co[8];
                 V3 t1, t2;
                 plane_space(nrm, t1, t2);
                 dir = col < MAXC ? nrm : (((col - MAXC) & 1) ? t2 : t1);
-                if (RC.body >= 0) {
-                    RC.myanc = M->anc_mask[RC.body];
-                    const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[RC.body]);
-                    RC.pw[0] = t.x; RC.pw[1] = t.y; RC.pw[2] = t.z;
+                if (R.body >= 0) {
+                    R.myanc = M->anc_mask[R.body];
+                    const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[R.body]);
+                    R.pw[0] = t.x; R.pw[1] = t.y; R.pw[2] = t.z;
                 }
-                if (RC.body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
-                    if (RC.body2 >= 0) {
-                        RC.myanc2 = M->anc_mask[RC.body2];
-                        const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[RC.body2]);
-                        RC.pw2[0] = t.x; RC.pw2[1] = t.y; RC.pw2[2] = t.z;
+                if (R.body2 >= -1) {          // both bodies belong to the robot: the base columns cancel
+                    if (R.body2 >= 0) {
+                        R.myanc2 = M->anc_mask[R.body2];
+                        const uint4 t = *reinterpret_cast<const uint4 *>(M->pathw[R.body2]);
+                        R.pw2[0] = t.x; R.pw2[1] = t.y; R.pw2[2] = t.z;
                     }
                 } else {
-                    RC.Jang = cross(pt - ld3(baseL + 9), dir);
-                    RC.Jlin = dir;
+                    R.Jang = cross(pt - ld3(baseL + 9), dir);
+                    R.Jlin = dir;
                 }
             }
-            // joint part of Jc: zero everywhere ...
-            {
-                float4 *z4 = reinterpret_cast<float4 *>(JcL + 6 * NC3);
-                float zero = 0.f;
-                asm volatile("" : "+v"(zero));       // materialised here: a hoisted zero quad would be spilled
-                #pragma unroll 1
-                // whole quads, rounded UP: (n * NC3) % 4 may be 2 (odd n with NC3 = 18); 6 * NC3 is a multiple of 4 and the
-                // region is sized rup4((6 + n) * NC3), so the last quad stays inside it
-                for (int k = lane; k < (n * NC3 + 3) / 4; k += WAVE) z4[k] = make_float4(zero, zero, zero, zero);
-            }
-            wave_sync();
-            // ... except on the path(s) from the contact bodies to the base: at most DEPTH entries per column
+            // joint part: non-zero only on the path(s) from the contact bodies to the base, at most DEPTH entries per column
             float rv = 0.f;
-            const bool two = __ballot(RC.myanc2 != 0ull) != 0ull;
-            if (RC.contact) {
+            const bool two = __ballot(R.myanc2 != 0ull) != 0ull;
+            if (R.contact) {
 #pragma unroll
                 for (int dd = 1; dd <= DEPTH; ++dd) {
                     if (dd <= maxlev) {      // wave-uniform
-                        const int l = (int)((RC.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        const int l = (int)((R.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                         if (l >= 0) {
                             const float *pcl = cacheL + CACHE * l;      // velocity of the point per unit joint rate: S.a x (pt - COM) + S.l
                             const Sv Sl = ldsv(pcl + C_SW);
@@ -698,7 +706,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                     for (int dd = 1; dd <= DEPTH; ++dd) {
                         if (dd <= maxlev) {
-                            const int l = (int)((RC.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                            const int l = (int)((R.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                             if (l >= 0) {
                                 const float *pcl = cacheL + CACHE * l;
                                 const Sv Sl = ldsv(pcl + C_SW);
@@ -711,19 +719,35 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
             }
             if (col >= 0) {
-                JcL[0 * NC3 + col] = RC.Jang.x; JcL[1 * NC3 + col] = RC.Jang.y; JcL[2 * NC3 + col] = RC.Jang.z;
-                JcL[3 * NC3 + col] = RC.Jlin.x; JcL[4 * NC3 + col] = RC.Jlin.y; JcL[5 * NC3 + col] = RC.Jlin.z;
-                rv += dot(RC.Jang, ld3(velL)) + dot(RC.Jlin, ld3(velL + 3));
+                JcL[0 * NC3 + col] = R.Jang.x; JcL[1 * NC3 + col] = R.Jang.y; JcL[2 * NC3 + col] = R.Jang.z;
+                JcL[3 * NC3 + col] = R.Jlin.x; JcL[4 * NC3 + col] = R.Jlin.y; JcL[5 * NC3 + col] = R.Jlin.z;
+                rv += dot(R.Jang, ld3(velL)) + dot(R.Jlin, ld3(velL + 3));
             }
-            if (RC.contact) {
+            if (R.contact) {
                 if (col < MAXC) {
-                    RC.target_err = -rv;
-                    if (dist > 0.f) RC.target_err -= dist * P.inv_dt;
-                    else RC.target_err -= dist * P.erp * P.inv_dt;
+                    R.target_err = -rv;
+                    if (dist > 0.f) R.target_err -= dist * P.inv_dt;
+                    else R.target_err -= dist * P.erp * P.inv_dt;
                 } else {
-                    RC.target_err = -rv;
+                    R.target_err = -rv;
                 }
             }
+        };
+        if (nc > 0) {
+            // joint part of Jc: zero everywhere ...
+            {
+                float4 *z4 = reinterpret_cast<float4 *>(JcL + 6 * NC3);
+                float zero = 0.f;
+                asm volatile("" : "+v"(zero));       // materialised here: a hoisted zero quad would be spilled
+                #pragma unroll 1
+                // whole quads, rounded UP: (n * NC3) % 4 may be 2 (odd n with NC3 = 18); 6 * NC3 is a multiple of 4 and the
+                // region is sized rup4((6 + n) * NC3), so the last quad stays inside it
+                for (int k = lane; k < (n * NC3 + 3) / 4; k += WAVE) z4[k] = make_float4(zero, zero, zero, zero);
+            }
+            wave_sync();
+            // ... except on the contact paths
+            contact_setup(RC);
+            if constexpr (NOV > 0) contact_setup(R1);      // also when inactive: the base part of their Jc columns must be written (zeros)
             // which links have a non-zero row in Jc: OR of the ancestor masks of the contact bodies, read
             // from the normal rows (lane CB + c) on the scalar unit
             {
@@ -772,7 +796,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // Jacobian slot_f = +-1 on joint slot_joint[k], so the impulse-response pass below computes its
         // A-row like any other lane's at no extra instruction.  Envs with more violated joints than
         // slots (and the variants with no spare lane, and the two-rows-per-lane variants) take the generic path in the solver.
-        constexpr int KL = DUAL ? 0 : ((WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4);
+        constexpr int KL = NROWS >= WAVE ? 0 : ((WAVE - NROWS) < 4 ? (WAVE - NROWS) : 4);
         const int nlim = __popcll(limmask);
         const bool use_slots = KL > 0 && nlim > 0 && nlim <= KL;      // wave-uniform
         int slot_joint[KL > 0 ? KL : 1];
@@ -806,6 +830,123 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         wave_sync();
 
         HG_TICK(7);
+        // ---- 4a'. overflow rows (OVF): what the sweep needs of a row without a lane ------------------------------------
+        // Row o = friction row of the last contact slot(s).  Its entries against the rows that HAVE a lane are those lanes'
+        // own column o (A is symmetric; every lane accumulates all NC3 contact columns in 4a).  What is left are its entries
+        // against the overflow rows themselves, diagonal included: J_o' is non-zero only on the paths of the overflow
+        // contacts' bodies, so the response M^-1 J_o^T is evaluated along those paths only (lane k < NOV: row NCL + k) --
+        // the own-path walk towards the root, the base, then one descent per contact body -- instead of over the whole tree.
+        // Results as wave-uniform scalars: ov_b (desired change of J.v), ov_inv (1 / A_oo, 0 = row disabled), ov_a[k][k'].
+        float ov_b[NOV > 0 ? NOV : 1], ov_inv[NOV > 0 ? NOV : 1], ov_a[NOV > 0 ? NOV : 1][NOV > 0 ? NOV : 1];
+#pragma unroll
+        for (int k = 0; k < (NOV > 0 ? NOV : 1); k++) {
+            ov_b[k] = 0.f; ov_inv[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < (NOV > 0 ? NOV : 1); j++) ov_a[k][j] = 0.f;
+        }
+        if constexpr (NOV > 0) {
+            if (ovf_on) {
+                const RowVars &R = R1;
+                const int col = R.col;
+                float XO[NOV], xdiag;
+                float Yo[DEPTH], Yo2[DEPTH];
+                Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
+#pragma unroll
+                for (int dd = DEPTH; dd >= 1; --dd) {
+                    float Y = 0.f;
+                    if (dd <= maxlev) {
+                        const int l = (int)((R.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        if (l >= 0) {
+                            const float *pc = cacheL + CACHE * l;
+                            Y = JcL[(6 + l) * NC3 + col] - sdot(ldsv(pc + C_SW), Z);
+                            Z = sfma(ldsv(pc + C_UW), Y * pc[C_DINV], Z);
+                            Z.a = Z.a + cross(ld3(pc + C_RW), Z.l);
+                        }
+                    }
+                    Yo[dd - 1] = Y;
+                }
+                const bool two = __ballot(R.myanc2 != 0ull) != 0ull;
+                Sv Z2; Z2.a = v3(0, 0, 0); Z2.l = v3(0, 0, 0);
+#pragma unroll
+                for (int dd = DEPTH; dd >= 1; --dd) {
+                    float Y = 0.f;
+                    if (two && dd <= maxlev) {
+                        const int l = (int)((R.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
+                        if (l >= 0) {
+                            const float *pc = cacheL + CACHE * l;
+                            const float f = ((R.myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];      // shared links: net entry taken on the first path
+                            Y = f - sdot(ldsv(pc + C_SW), Z2);
+                            Z2 = sfma(ldsv(pc + C_UW), Y * pc[C_DINV], Z2);
+                            Z2.a = Z2.a + cross(ld3(pc + C_RW), Z2.l);
+                        }
+                    }
+                    Yo2[dd - 1] = Y;
+                }
+                Z = Z + Z2;
+                Z.a = Z.a - R.Jang;
+                Z.l = Z.l - R.Jlin;
+                const Sv ab = neg_mul6(baseL + 12, Z);
+                xdiag = dot(ab.a, R.Jang) + dot(ab.l, R.Jlin);
+                {
+                    const float ub[6] = {ab.a.x, ab.a.y, ab.a.z, ab.l.x, ab.l.y, ab.l.z};
+#pragma unroll
+                    for (int j = 0; j < NOV; j++) {
+                        float x = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) x = fmaf(ub[k], JcL[k * NC3 + NCL + j], x);
+                        XO[j] = x;
+                    }
+                }
+                // descents: the path of every body of every overflow contact (wave-uniform links, read from the lane that
+                // owns the contact's first friction row); a link met again on a later path is not accumulated twice
+                unsigned vis_lo = 0u, vis_hi = 0u;
+#pragma unroll
+                for (int oc = 0; oc < NOV / 2; ++oc) {
+                    if (OC0 + oc < nc) {
+#pragma unroll
+                        for (int which = 0; which < 2; ++which) {
+                            unsigned pwu[3];
+#pragma unroll
+                            for (int j = 0; j < 3; j++)
+                                pwu[j] = (unsigned)__builtin_amdgcn_readlane((int)(which ? R.pw2[j] : R.pw[j]), 2 * oc);
+                            Sv a = ab;
+#pragma unroll
+                            for (int dd = 1; dd <= DEPTH; ++dd) {
+                                if (dd <= maxlev) {
+                                    const int l = (int)((pwu[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;      // scalar
+                                    if (l >= 0) {
+                                        const float *pc = cacheL + CACHE * l;
+                                        a.l = a.l + cross(a.a, ld3(pc + C_RW));
+                                        const bool on1 = ((l < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (l & 31)) & 1u;
+                                        const bool on2 = ((l < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (l & 31)) & 1u;
+                                        const float Y = (on1 ? Yo[dd - 1] : 0.f) + (on2 ? Yo2[dd - 1] : 0.f);
+                                        const float qa = (Y - sdot(ldsv(pc + C_UW), a)) * pc[C_DINV];
+                                        a = sfma(ldsv(pc + C_SW), qa, a);
+                                        const bool seen = ((l < 32 ? vis_lo : vis_hi) >> (l & 31)) & 1u;
+                                        if (!seen) {
+                                            const float *jr = JcL + (6 + l) * NC3;
+#pragma unroll
+                                            for (int j = 0; j < NOV; j++) XO[j] = fmaf(qa, jr[NCL + j], XO[j]);
+                                            if (col >= 0) xdiag = fmaf(qa, jr[col], xdiag);
+                                        }
+                                        if (l < 32) vis_lo |= 1u << l; else vis_hi |= 1u << (l - 32);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                const float inv = (R.contact && xdiag > (float)HG_ROW_DEN_EPS) ? __frcp_rn(xdiag) : 0.f;      // else: row disabled
+#pragma unroll
+                for (int k = 0; k < NOV; k++) {
+                    ov_b[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R.target_err), k));
+                    ov_inv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), k));
+#pragma unroll
+                    for (int j = 0; j < NOV; j++)
+                        ov_a[k][j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(XO[j]), k));
+                }
+            }
+        }
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
         // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
         // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
@@ -887,12 +1028,14 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                     for (int c = 0; c < NC3; c++) XC[c] = fmaf(ub[k], JcL[k * NC3 + c], XC[c]);
             }
-            // (iii) full descent: joint accelerations of every link for this row's impulse
-            Sv acur = ab, slot[NSL > 0 ? NSL : 1];
+            // (iii) full descent: joint accelerations of every link for this row's impulse.  Unrolled over the links: the link
+            // index is a compile-time constant (the motor column is a named register, the cache record a constant LDS
+            // offset, its topology word one v_readlane); what stays run-time is the topology itself.
+            static_assert(NSL <= 2, "saved-acceleration slots are two named registers sets");
+            Sv acur = ab, slot0 = ab, slot1 = ab;      // (named, not an array: nothing of the descent may end up in scratch)
 #pragma unroll
-            for (int s = 0; s < NSL; s++) slot[s] = ab;
-            #pragma unroll 1
-            for (int i = 0; i < n; ++i) {
+            for (int i = 0; i < NMX; ++i) {      // (a plain loop, fully unrolled: a closure per link sent the slots to scratch)
+                if (i < n) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
                 const int mode = (int)(inf & 0xffu);
                 const float *pc = cacheL + CACHE * i;
@@ -901,44 +1044,53 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 Sv a;
                 if (mode == 0) a = acur;
                 else if (mode == 1) a = ab;
-                else {
-                    a = ab;
-#pragma unroll
-                    for (int s = 0; s < NSL; s++) if (mode == 2 + s) a = slot[s];
-                }
-                a.l = a.l + cross(a.a, ld3(pc + C_RW));        // the same acceleration at this link's origin
+                else if (NSL > 0 && mode == 2) a = slot0;
+                else if (NSL > 1 && mode == 3) a = slot1;
+                else a = ab;
+                // the cache record [0:16): r_w, 1/D, U, S as four 16-byte LDS reads
+                const float4 c0 = *reinterpret_cast<const float4 *>(pc), c1 = *reinterpret_cast<const float4 *>(pc + 4),
+                             c2 = *reinterpret_cast<const float4 *>(pc + 8), c3 = *reinterpret_cast<const float4 *>(pc + 12);
+                static_assert(C_RW == 0 && C_DINV == 3 && C_UW == 4 && C_SW == 10, "cache record layout");
+                a.l = a.l + cross(a.a, v3(c0.x, c0.y, c0.z));        // the same acceleration at this link's origin
                 // Y of this link: non-zero only if it is the own-path link of its depth d (wave-uniform)
                 const int d = (int)((inf >> 8) & 0xffu);
-                bool on_path;              // bit i of the ancestor mask, as 32-bit operations (i is wave-uniform)
-                if constexpr (NMX <= 32) on_path = (((unsigned)R.myanc >> i) & 1u) != 0u;
-                else on_path = (((i < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (i & 31)) & 1u) != 0u;
+                const bool on_path = (((i < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (i & 31)) & 1u) != 0u;
                 float Y = 0.f;
                 if constexpr (YSL) { const float y = ysL[(d - 1) * WAVE + lane]; Y = on_path ? y : 0.f; }      // own lane's value: no sync
                 else { switch (d) { HG_Y_CASES default: break; } }
                 if (R.two_body) {          // myanc2 != 0 only on contact-row lanes
-                    bool on2;
-                    if constexpr (NMX <= 32) on2 = (((unsigned)R.myanc2 >> i) & 1u) != 0u;
-                    else on2 = (((i < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (i & 31)) & 1u) != 0u;
+                    const bool on2 = (((i < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (i & 31)) & 1u) != 0u;
                     if (on2) Y += Yd2L[(d - 1) * NC3 + col];
                 }
-                const float qa = (Y - sdot(ldsv(pc + C_UW), a)) * pc[C_DINV];
-                a = sfma(ldsv(pc + C_SW), qa, a);
+                Sv Uw, Swv;
+                Uw.a = v3(c1.x, c1.y, c1.z); Uw.l = v3(c1.w, c2.x, c2.y);
+                Swv.a = v3(c2.z, c2.w, c3.x); Swv.l = v3(c3.y, c3.z, c3.w);
+                const float qa = (Y - sdot(Uw, a)) * c0.w;
+                a = sfma(Swv, qa, a);
                 acur = a;
                 const int sv = (int)((inf >> 16) & 0xffu) - 1;
-                if (sv >= 0) {
-#pragma unroll
-                    for (int s = 0; s < NSL; s++) if (sv == s) slot[s] = a;
-                }
-                if constexpr (NMX <= 16) XM0[i] = qa;
-                else if constexpr (NMX <= 32) { if (i < 16) XM0[i] = qa; else XM1[i - 16] = qa; }
-                else if constexpr (NMX <= 48) { if (i < 16) XM0[i] = qa; else if (i < 32) XM1[i - 16] = qa; else XM2[i - 32] = qa; }
-                else { if (i < 16) XM0[i] = qa; else if (i < 32) XM1[i - 16] = qa; else if (i < 48) XM2[i - 32] = qa; else XM3[i - 48] = qa; }
-                if (i == body && unit_row) xdiag = R.unit_f * qa;
+                if (NSL > 0 && sv == 0) slot0 = a;
+                if (NSL > 1 && sv == 1) slot1 = a;
+                if (i < 16) XM0[i % clamp16(NMX)] = qa;
+                else if (i < 32) XM1[(i - 16) % clamp16(NMX - 16)] = qa;
+                else if (i < 48) XM2[(i - 32) % clamp16(NMX - 32)] = qa;
+                else XM3[(i - 48) % clamp16(NMX - 48)] = qa;
+                if (unit_row && i == body) xdiag = R.unit_f * qa;
                 if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
+                    if constexpr (NC3 % 4 == 0) {
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) XC[c] = fmaf(qa, jr[c], XC[c]);
+                        for (int c = 0; c < NC3; c += 4) {
+                            const float4 j4 = *reinterpret_cast<const float4 *>(jr + c);
+                            XC[c] = fmaf(qa, j4.x, XC[c]); XC[c + 1] = fmaf(qa, j4.y, XC[c + 1]);
+                            XC[c + 2] = fmaf(qa, j4.z, XC[c + 2]); XC[c + 3] = fmaf(qa, j4.w, XC[c + 3]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NC3; c++) XC[c] = fmaf(qa, jr[c], XC[c]);
+                    }
                     if (col >= 0) xdiag = fmaf(qa, jr[col], xdiag);
+                }
                 }
             }
         };
@@ -977,6 +1129,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // z_i unchanged, so the sweep needs one med3, one readlane and two fmas (- old, + new impulse) per
         // row.  Same iterates as Bullet's velocity-space sweep over deltaV.
         float z, lo = 0.f, hi = 0.f;
+        float AOr[NOV > 0 ? NOV : 1];       // OVF: this lane's raw entries against the overflow rows, A[lane row][o]
+#pragma unroll
+        for (int k = 0; k < (NOV > 0 ? NOV : 1); k++) AOr[k] = NOV > 0 ? AC[NOV > 0 ? NCL + k : 0] : 0.f;
         {
             const float dinv = (row_active && diag > (float)HG_ROW_DEN_EPS) ? __frcp_rn(diag) : 0.f;      // else: row disabled (hg_model.h)
             z = target_err * dinv;
@@ -996,7 +1151,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         float lam_l = 0.f;
         float lam = 0.f;            // impulse of this lane's (set-0) row once the sweeps are done
 
-        if constexpr (!DUAL) {
+        if constexpr (NROWS <= WAVE) {
         // The slot rows bring one more column each: aL[k][j] = -A[j][L_k] / A[j][j] = slot_sign * (column i_k),
         // except on the joint's own motor lane (-slot_sign: same Jacobian entry, A[i][L] = sign * A[i][i]) and on
         // the slot lane itself (0, the diagonal).
@@ -1166,6 +1321,134 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
         }
         lamL[lane] = fmaf(lim_s, lam_l, lam);      // joint impulse = motor row + (signed) limit row; contact lanes: their own impulse
+        } else if constexpr (NOV > 0) {
+        // ---- 4b, one row per lane plus overflow rows.  The impulses of the rows that have a lane live in a VGPR (lane j: the
+        // impulse of its row; 64 of them do not fit the scalar register file) and a row update broadcasts the CHANGE of its impulse:
+        //   cand = med3(z, lo, hi);  s_d = readlane(cand - lam, i);  z += A_i s_d;  lam_i = cand  (one-lane EXEC move)
+        // Overflow rows: an overflow row o is updated from
+        //   z_o = (b_o - sum_j A[j][o] lam_j - sum_{o' != o} A[o][o'] lam_o') / A[o][o],
+        // the first sum over the rows with a lane -- one multiply per lane and a wave reduction (DPP) -- and its change is
+        // then applied to every lane's candidate like any other row's.  Same iterates, same row order as Bullet's sweep (the
+        // friction pair of the last contact slot is the last pair of the sweep).  Violated joint limits take the run-time
+        // loop (a limit row lives on its joint's motor lane, see the one-row-per-lane solver above for the algebra).
+        float lamv0 = 0.f;
+        float lamo[NOV];
+#pragma unroll
+        for (int k = 0; k < NOV; k++) lamo[k] = 0.f;
+        float mu_s = P.mu;
+        asm volatile("" : "+s"(mu_s));
+        float mu_v = mu_s;
+        asm volatile("" : "+v"(mu_v));
+        const float lim_k = lim_b - lim_s * z;      // z is still b_m / A_ii here
+        auto colA = [&](const int i) -> float {     // compile-time i
+            if (i < 16) return AM0[i < 16 ? i : 0];
+            else if (i < 32) return AM1[i >= 16 && i < 32 && i < NMX ? i - 16 : 0];
+            else if (i < 48) return AM2[i >= 32 && i < 48 && i < NMX ? i - 32 : 0];
+            else return AM3[i >= 48 && i < NMX ? i - 48 : 0];
+        };
+        // One row update as one block of seven issue slots (a lone wave issues an instruction every 5-6 clocks whatever its
+        // kind, and the waves of these shapes run nearly alone: slots are what counts).  Wait states of gfx950 respected by
+        // hand: one between a VALU write of a VGPR and v_readlane of it, two between v_readlane's SGPR and its VALU use;
+        // lam_i = cand on lane i alone is a select under a one-lane mask built on the scalar unit, placed in those gaps.
+        auto lane_row_update = [&](const int i, const float a_i, const float rlo, const float rhi) {      // row on lane i (compile-time)
+            float cand, d; int sd; unsigned long long m1;
+            asm("v_med3_f32 %2, %0, %7, %8\n\tv_sub_f32 %3, %2, %1\n\ts_lshl_b64 %5, 1, %9\n\tv_readlane_b32 %4, %3, %9\n\t"
+                "v_cndmask_b32_e64 %1, %1, %2, %5\n\ts_nop 0\n\tv_fmac_f32 %0, %4, %6"
+                : "+v"(z), "+v"(lamv0), "=&v"(cand), "=&v"(d), "=&s"(sd), "=&s"(m1) : "v"(a_i), "v"(rlo), "v"(rhi), "n"(i) : "scc");      // s_lshl writes SCC
+        };
+        auto lane_row_update_sym = [&](const int i, const float a_i, const float lim) {      // bounds -lim, lim
+            float cand, d; int sd; unsigned long long m1;
+            asm("v_med3_f32 %2, %0, -%7, %7\n\tv_sub_f32 %3, %2, %1\n\ts_lshl_b64 %5, 1, %8\n\tv_readlane_b32 %4, %3, %8\n\t"
+                "v_cndmask_b32_e64 %1, %1, %2, %5\n\ts_nop 0\n\tv_fmac_f32 %0, %4, %6"
+                : "+v"(z), "+v"(lamv0), "=&v"(cand), "=&v"(d), "=&s"(sd), "=&s"(m1) : "v"(a_i), "v"(lim), "n"(i) : "scc");
+        };
+        auto wave_sum = [&](float x) -> float {      // sum over the 64 lanes, wave-uniform result
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));      // row_ror:2
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));      // row_ror:1: every lane holds its row's sum
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1, 3
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2, 3
+            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+        };
+        auto overflow_pair = [&](const int k, const float lim) {      // overflow rows k, k + 1: the friction pair of one contact
+            const float lt = fmaf(lim_s, lam_l, lamv0);               // joint impulse on motor lanes, the row's own elsewhere
+            const float S0 = wave_sum(AOr[k] * lt), S1 = wave_sum(AOr[k + 1] * lt);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                float acc = ov_b[k + r] - (r ? S1 : S0);
+#pragma unroll
+                for (int j = 0; j < NOV; j++) if (j != k + r) acc = fmaf(-ov_a[k + r][j], lamo[j], acc);
+                const float cand = __builtin_amdgcn_fmed3f(acc * ov_inv[k + r], -lim, lim);
+                const float d = cand - lamo[k + r];
+                lamo[k + r] = cand;
+                z = fmaf(AC[NCL + k + r], d, z);
+            }
+        };
+        auto contact_rows = [&]() {
+            if (nc > 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) lane_row_update(NMX + c, AC[c], lo, hi);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) {
+                        const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lamv0), NMX + c);
+                        if (tot_i > 0) {                      // tot > 0 on the scalar unit (positive float bits)
+                            const float lim = mu_v * __int_as_float(tot_i);
+                            if constexpr (true) {
+                                if (MAXC + 2 * c + 1 < NCL) {
+                                    lane_row_update_sym(NMX + MAXC + 2 * c, AC[MAXC + 2 * c < NCL ? MAXC + 2 * c : 0], lim);
+                                    lane_row_update_sym(NMX + MAXC + 2 * c + 1, AC[MAXC + 2 * c + 1 < NCL ? MAXC + 2 * c + 1 : 0], lim);
+                                } else {
+                                    overflow_pair(MAXC + 2 * c >= NCL ? MAXC + 2 * c - NCL : 0, lim);
+                                }
+                            }
+                        }
+                    }
+            }
+        };
+        auto limit_update_idx = [&](const int i) __attribute__((always_inline)) {   // i: wave-uniform, known at run time
+            const float zl = lam_l + lim_k + lim_s * (z - lamv0);
+            const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), i));
+            const int j = i & 15;
+            float a_i;
+            if (i < 16) a_i = AM0[j % clamp16(NMX)];
+            else if (i < 32) a_i = AM1[j % clamp16(NMX - 16)];
+            else if (i < 48) a_i = AM2[j % clamp16(NMX - 32)];
+            else a_i = AM3[j % clamp16(NMX - 48)];
+            z = fmaf(a_i, d, z);                            // a_ii = 0: lane i is handled next
+            if (lane == i) { lam_l = cand; z -= d; }
+        };
+        auto sweep3 = [&](const bool forward) {
+            if (forward) {
+                #pragma unroll 1
+                for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update_idx(__builtin_ctzll(mk));
+#pragma unroll
+                for (int i = 0; i < NMX; ++i) lane_row_update(i, colA(i), lo, hi);
+            } else {
+#pragma unroll
+                for (int i = NMX - 1; i >= 0; --i) lane_row_update(i, colA(i), lo, hi);
+                #pragma unroll 1
+                for (unsigned long long mk = limmask; mk != 0ull;) {
+                    const int i = 63 - __builtin_clzll(mk);
+                    limit_update_idx(i);
+                    mk &= ~(1ull << i);
+                }
+            }
+            contact_rows();
+        };
+        #pragma unroll 1
+        for (int it = 0; it + 1 < P.iters; it += 2) { sweep3(false); sweep3(true); }
+        if (P.iters & 1) sweep3(false);
+        HG_TICK(9);
+        lam = lamv0;
+        lamL[lane] = fmaf(lim_s, lam_l, lamv0);      // joint impulse = motor row + (signed) limit row; contact lanes: their own impulse
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < NOV; k++) lamL[NMX + NCL + k] = lamo[k];
+        }
         } else {
         // ---- 4b, two rows per lane.  The impulses live in VGPRs (lane i of lamv0: motor i, lane c of lamv1: contact
         // row c; 66-98 of them would not fit the scalar register file), and a row update broadcasts the CHANGE of its impulse:

@@ -229,14 +229,14 @@ def test_hands_envs_and_full_size_invariants():
 
 @pytest.mark.parametrize("robot,variant,cfg_kw", [
     ("nao", 2, {}), ("nao", 3, dict(max_contacts=12)), ("nao", 6, dict(max_contacts=12)), ("nao", 7, {}), ("nao", 8, {}),
-    ("nao", 9, dict(max_contacts=6)), ("nao", 10, {}), ("nao", 11, {}), ("nao", 12, dict(max_contacts=12)),
-    ("pepper", 5, {}), ("pepper", 6, {}), ("pepper", 10, {}), ("dancer", 3, {}), ("dancer", 12, {}),
+    ("nao", 9, dict(max_contacts=6)), ("nao", 10, {}), ("nao", 11, {}), ("nao", 12, {}), ("nao", 13, dict(max_contacts=12)),
+    ("pepper", 5, {}), ("pepper", 6, {}), ("pepper", 10, {}), ("pepper", 11, {}), ("dancer", 3, {}), ("dancer", 13, {}),
 ])
 def test_every_kernel_instantiation_agrees_with_the_oracle(robot, variant, cfg_kw, monkeypatch):
-    """hg_sim.hip instantiates 13 shapes of the step kernel; the four robots and the two hands models pick 0, 1, 4, 7,
-    10 and 11 by themselves.  HG_VARIANT (a diagnostics override read by hg_create) forces the others -- and the
-    two-rows-per-lane shapes 10-12 onto robots that normally run one row per lane -- so that every compiled shape is
-    held to the same one-step bar."""
+    """hg_sim.hip instantiates 14 shapes of the step kernel; the four robots and the two hands models pick 0, 1, 4, 7,
+    10 and 12 by themselves.  HG_VARIANT (a diagnostics override read by hg_create) forces the others -- and the
+    overflow-row shape 10 and the two-rows-per-lane shapes 11-13 onto robots that normally run one row per lane -- so
+    that every compiled shape is held to the same one-step bar."""
     import torch
     from humanoid_gym_amd._capi import HgSim
     monkeypatch.setenv("HG_VARIANT", str(variant))

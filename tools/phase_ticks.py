@@ -20,10 +20,8 @@ PHASES = ["prologue: topology tables, targets", "state + link constants, sin/cos
           "impulses -> joints, final response", "integration, state store", "epilogue: guard, observations, flags"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
-    from humanoid_gym_amd.build import HIPCC_FLAGS
-    cmd = ["/opt/rocm/bin/hipcc", *HIPCC_FLAGS, "-DHG_PHASE_TIMING", "hg_sim.hip", "-o", LIB]
-    print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    from humanoid_gym_amd.build import build
+    print(build(force="--force" in sys.argv, verbose=True, lib=LIB, extra_flags=["-DHG_PHASE_TIMING"], obj_dir="_obj_ticks"))
     sys.exit(0)
 
 import numpy as np
