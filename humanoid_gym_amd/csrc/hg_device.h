@@ -10,6 +10,11 @@
 #include <stdint.h>
 #include "../../include/hg_model.h"
 
+#ifdef HG_PHASE_TIMING      // diagnostics build (tools/phase_ticks.py)
+#define HG_TICK_ENVS 4096
+#define HG_TICK_SLOTS 16
+#endif
+
 namespace hg {
 
 constexpr int WAVE  = 64;

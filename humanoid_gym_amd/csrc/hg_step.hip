@@ -42,8 +42,6 @@ namespace hg {
 // Diagnostics build only (-DHG_PHASE_TIMING, tools/phase_ticks.py): lane 0 of the first envs writes the
 // shader clock at every phase boundary.  The product library is built without it.
 #ifdef HG_PHASE_TIMING
-#define HG_TICK_ENVS 4096
-#define HG_TICK_SLOTS 16
 static __device__ unsigned long long hg_ticks[HG_TICK_ENVS][HG_TICK_SLOTS];
 #define HG_TICK(K) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
         if (threadIdx.x == 0 && blockIdx.x < HG_TICK_ENVS) hg_ticks[blockIdx.x][K] = t_; } while (0)
@@ -88,6 +86,13 @@ HG_FI void wave_sync() {
 #define HG_Y_CASE(K) case K + 1: if constexpr (K < DEPTH) { Y = on_path ? Ys[K < YSN ? K : 0] : 0.f; } break;
 #define HG_Y_CASES HG_Y_CASE(0) HG_Y_CASE(1) HG_Y_CASE(2) HG_Y_CASE(3) HG_Y_CASE(4) HG_Y_CASE(5) \
                    HG_Y_CASE(6) HG_Y_CASE(7) HG_Y_CASE(8) HG_Y_CASE(9) HG_Y_CASE(10) HG_Y_CASE(11)
+
+// One PGS row update of the lane-impulse form as assembly text (seven issue slots; see "4b, one row per lane plus overflow
+// rows"): operands z, l (lane impulses), c, d (temporaries), s (SGPR), m (SGPR pair), lo, hi, a<K> (column), lane i0 SGN K.
+#define HG_ROW_ASM(K, SGN) "v_med3_f32 %[c], %[z], %[lo], %[hi]\n\tv_sub_f32 %[d], %[c], %[l]\n\ts_lshl_b64 %[m], 1, %[i0]" SGN #K "\n\t" \
+    "v_readlane_b32 %[s], %[d], %[i0]" SGN #K "\n\tv_cndmask_b32_e64 %[l], %[l], %[c], %[m]\n\ts_nop 0\n\tv_fmac_f32 %[z], %[s], %[a" #K "]\n\t"
+#define HG_ROWS2_ASM(SGN) HG_ROW_ASM(0, SGN) HG_ROW_ASM(1, SGN)
+#define HG_ROWS6_ASM(SGN) HG_ROW_ASM(0, SGN) HG_ROW_ASM(1, SGN) HG_ROW_ASM(2, SGN) HG_ROW_ASM(3, SGN) HG_ROW_ASM(4, SGN) HG_ROW_ASM(5, SGN)
 
 // compile-time loop: f(IC<I>{}) for I = B .. E-1
 template <int I> struct IC { static constexpr int value = I; };
@@ -1362,6 +1367,46 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 "v_cndmask_b32_e64 %1, %1, %2, %5\n\ts_nop 0\n\tv_fmac_f32 %0, %4, %6"
                 : "+v"(z), "+v"(lamv0), "=&v"(cand), "=&v"(d), "=&s"(sd), "=&s"(m1) : "v"(a_i), "v"(lim), "n"(i) : "scc");
         };
+        // Several rows on consecutive lanes as ONE block of assembly (hipcc puts a wait state between two asm statements):
+        // lanes i0, i0 +- 1, ... with the columns a0 .. ; forward or backward.
+        auto rows6 = [&](const int i0, const bool fwd, const float a0, const float a1, const float a2, const float a3, const float a4,
+                         const float a5, const float rlo, const float rhi) {
+            float cand, d; int sd; unsigned long long m1;
+            if (fwd)
+                asm(HG_ROWS6_ASM("+") : [z] "+v"(z), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5), [lo] "v"(rlo), [hi] "v"(rhi), [i0] "n"(i0) : "scc");
+            else
+                asm(HG_ROWS6_ASM("-") : [z] "+v"(z), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5), [lo] "v"(rlo), [hi] "v"(rhi), [i0] "n"(i0) : "scc");
+        };
+        auto rows2 = [&](const int i0, const bool fwd, const float a0, const float a1, const float rlo, const float rhi) {
+            float cand, d; int sd; unsigned long long m1;
+            if (fwd)
+                asm(HG_ROWS2_ASM("+") : [z] "+v"(z), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(a0), [a1] "v"(a1), [lo] "v"(rlo), [hi] "v"(rhi), [i0] "n"(i0) : "scc");
+            else
+                asm(HG_ROWS2_ASM("-") : [z] "+v"(z), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(a0), [a1] "v"(a1), [lo] "v"(rlo), [hi] "v"(rhi), [i0] "n"(i0) : "scc");
+        };
+        // rows on lanes [b, b + cnt) with the columns col(k), k = 0 .. cnt - 1, in blocks of 6, 2 and 1; ascending or descending
+        auto row_run = [&](const int b, const int cnt, const bool fwd, auto col) __attribute__((always_inline)) {
+            int k = 0;
+#pragma unroll
+            for (; k + 6 <= cnt; k += 6) {
+                const int j = fwd ? k : cnt - 1 - k, sg = fwd ? 1 : -1;
+                rows6(b + j, fwd, col(j), col(j + sg), col(j + 2 * sg), col(j + 3 * sg), col(j + 4 * sg), col(j + 5 * sg), lo, hi);
+            }
+#pragma unroll
+            for (; k + 2 <= cnt; k += 2) {
+                const int j = fwd ? k : cnt - 1 - k, sg = fwd ? 1 : -1;
+                rows2(b + j, fwd, col(j), col(j + sg), lo, hi);
+            }
+#pragma unroll
+            for (; k < cnt; k += 1) {
+                const int j = fwd ? k : cnt - 1 - k;
+                lane_row_update(b + j, col(j), lo, hi);
+            }
+        };
         auto wave_sum = [&](float x) -> float {      // sum over the 64 lanes, wave-uniform result
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
             x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
@@ -1387,9 +1432,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         };
         auto contact_rows = [&]() {
             if (nc > 0) {
+                if (nc == MAXC) {       // every slot taken (a robot standing on two feet): the normals as one run, no tests
+                    row_run(NMX, MAXC, true, [&](const int c) -> float { return AC[c >= 0 && c < MAXC ? c : 0]; });
+                } else {
 #pragma unroll
-                for (int c = 0; c < MAXC; ++c)
-                    if (c < nc) lane_row_update(NMX + c, AC[c], lo, hi);
+                    for (int c = 0; c < MAXC; ++c)
+                        if (c < nc) lane_row_update(NMX + c, AC[c], lo, hi);
+                }
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
                     if (c < nc) {
@@ -1421,20 +1470,65 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             z = fmaf(a_i, d, z);                            // a_ii = 0: lane i is handled next
             if (lane == i) { lam_l = cand; z -= d; }
         };
+        // Up to KLG violated joint limits (the finger-joint models rest a few fingers ON a bound: the common case): the column
+        // of limit row k -- that of its joint's motor row, with -1 on the joint's own lane, which takes the change of the
+        // JOINT impulse off the motor row's candidate -- is fetched ONCE per step with an indexed register read; the sweep then
+        // runs the rows with compile-time k.  More violated joints than that: the run-time loop with indexed reads per sweep.
+        constexpr int KLG = 4;
+        const int nlim_g = __popcll(limmask);
+        const bool lim_gathered = nlim_g > 0 && nlim_g <= KLG;        // wave-uniform
+        float alim[KLG];
+        int lim_joint[KLG];
+        unsigned long long lim_bit[KLG];
+#pragma unroll
+        for (int k = 0; k < KLG; k++) { alim[k] = 0.f; lim_joint[k] = 0; lim_bit[k] = 0ull; }
+        if (lim_gathered) {
+            unsigned long long mk = limmask;
+#pragma unroll
+            for (int k = 0; k < KLG; k++) {
+                if (k < nlim_g) {
+                    const int i = __builtin_ctzll(mk);
+                    mk &= mk - 1ull;
+                    const int j = i & 15;
+                    float a_i;
+                    if (i < 16) a_i = AM0[j % clamp16(NMX)];
+                    else if (i < 32) a_i = AM1[j % clamp16(NMX - 16)];
+                    else if (i < 48) a_i = AM2[j % clamp16(NMX - 32)];
+                    else a_i = AM3[j % clamp16(NMX - 48)];
+                    alim[k] = lane == i ? -1.f : a_i;
+                    lim_joint[k] = i; lim_bit[k] = 1ull << i;
+                }
+            }
+        }
+        auto limit_update_g = [&](const int k) {           // compile-time k; the row lives on lane lim_joint[k]
+            const float zl = fmaf(lim_s, z - lamv0, lam_l) + lim_k;
+            const float cand = __builtin_amdgcn_fmed3f(zl, 0.f, P.limhi);
+            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lim_s * (cand - lam_l)), lim_joint[k]));
+            z = fmaf(alim[k], d, z);
+            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lam_l) : "v"(cand), "s"(lim_bit[k]));
+        };
         auto sweep3 = [&](const bool forward) {
             if (forward) {
-                #pragma unroll 1
-                for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update_idx(__builtin_ctzll(mk));
+                if (lim_gathered) {
 #pragma unroll
-                for (int i = 0; i < NMX; ++i) lane_row_update(i, colA(i), lo, hi);
+                    for (int k = 0; k < KLG; ++k) if (k < nlim_g) limit_update_g(k);
+                } else {
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update_idx(__builtin_ctzll(mk));
+                }
+                row_run(0, NMX, true, colA);
             } else {
+                row_run(0, NMX, false, colA);
+                if (lim_gathered) {
 #pragma unroll
-                for (int i = NMX - 1; i >= 0; --i) lane_row_update(i, colA(i), lo, hi);
-                #pragma unroll 1
-                for (unsigned long long mk = limmask; mk != 0ull;) {
-                    const int i = 63 - __builtin_clzll(mk);
-                    limit_update_idx(i);
-                    mk &= ~(1ull << i);
+                    for (int k = KLG - 1; k >= 0; --k) if (k < nlim_g) limit_update_g(k);
+                } else {
+                    #pragma unroll 1
+                    for (unsigned long long mk = limmask; mk != 0ull;) {
+                        const int i = 63 - __builtin_clzll(mk);
+                        limit_update_idx(i);
+                        mk &= ~(1ull << i);
+                    }
                 }
             }
             contact_rows();
