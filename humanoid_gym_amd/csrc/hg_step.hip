@@ -956,6 +956,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
         // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
         // instead of a 64-way switch; contact columns: plain registers, compile-time indices only.
+        HG_TICK(15);      // end of the overflow rows' path-only response (4a')
         typedef typename RegVec<clamp16(NMX)>::type VA0;
         typedef typename RegVec<clamp16(NMX - 16)>::type VA1;
         typedef typename RegVec<clamp16(NMX - 32)>::type VA2;
@@ -1036,22 +1037,30 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             // (iii) full descent: joint accelerations of every link for this row's impulse.  Unrolled over the links: the link
             // index is a compile-time constant (the motor column is a named register, the cache record a constant LDS
             // offset, its topology word one v_readlane); what stays run-time is the topology itself.
-            static_assert(NSL <= 2, "saved-acceleration slots are two named registers sets");
-            Sv acur = ab, slot0 = ab, slot1 = ab;      // (named, not an array: nothing of the descent may end up in scratch)
+            // Parent acceleration of a link: the previous link's (mode 0: `a` simply stays in its registers), the base's, or that
+            // of a saved branching link -- picked with selects under scalar conditions inside ONE uniform branch, so that a
+            // chain link (the common case) pays nothing and nothing is copied at a merge point.
+            static_assert(NSL <= 2, "two saved-acceleration slots");
+            Sv a = ab, slot0 = ab, slot1 = ab;
+            // own-path Y values by depth in one register vector, read with the link's depth as index
+            typedef float V16f __attribute__((ext_vector_type(16)));
+            V16f Yv = (V16f)(0.f);
+            if constexpr (!YSL) {
+#pragma unroll
+                for (int k = 0; k < DEPTH; k++) Yv[k] = Ys[k < YSN ? k : 0];
+            }
 #pragma unroll
             for (int i = 0; i < NMX; ++i) {      // (a plain loop, fully unrolled: a closure per link sent the slots to scratch)
                 if (i < n) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
-                const int mode = (int)(inf & 0xffu);
+                const int mode = (int)(inf & 0x3u);
                 const float *pc = cacheL + CACHE * i;
-                // parent acceleration: previous link, base, or a saved branching link -- a scalar branch
-                // per case (mode is wave-uniform), so no register copies are needed to pick one
-                Sv a;
-                if (mode == 0) a = acur;
-                else if (mode == 1) a = ab;
-                else if (NSL > 0 && mode == 2) a = slot0;
-                else if (NSL > 1 && mode == 3) a = slot1;
-                else a = ab;
+                if (mode != 0) {
+                    const bool m2 = NSL > 0 && mode == 2, m3 = NSL > 1 && mode == 3;
+                    a.a.x = m3 ? slot1.a.x : (m2 ? slot0.a.x : ab.a.x); a.a.y = m3 ? slot1.a.y : (m2 ? slot0.a.y : ab.a.y);
+                    a.a.z = m3 ? slot1.a.z : (m2 ? slot0.a.z : ab.a.z); a.l.x = m3 ? slot1.l.x : (m2 ? slot0.l.x : ab.l.x);
+                    a.l.y = m3 ? slot1.l.y : (m2 ? slot0.l.y : ab.l.y); a.l.z = m3 ? slot1.l.z : (m2 ? slot0.l.z : ab.l.z);
+                }
                 // the cache record [0:16): r_w, 1/D, U, S as four 16-byte LDS reads
                 const float4 c0 = *reinterpret_cast<const float4 *>(pc), c1 = *reinterpret_cast<const float4 *>(pc + 4),
                              c2 = *reinterpret_cast<const float4 *>(pc + 8), c3 = *reinterpret_cast<const float4 *>(pc + 12);
@@ -1062,7 +1071,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 const bool on_path = (((i < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (i & 31)) & 1u) != 0u;
                 float Y = 0.f;
                 if constexpr (YSL) { const float y = ysL[(d - 1) * WAVE + lane]; Y = on_path ? y : 0.f; }      // own lane's value: no sync
-                else { switch (d) { HG_Y_CASES default: break; } }
+                else { const float y = Yv[(d - 1) & 15]; Y = on_path ? y : 0.f; }
                 if (R.two_body) {          // myanc2 != 0 only on contact-row lanes
                     const bool on2 = (((i < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (i & 31)) & 1u) != 0u;
                     if (on2) Y += Yd2L[(d - 1) * NC3 + col];
@@ -1072,10 +1081,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 Swv.a = v3(c2.z, c2.w, c3.x); Swv.l = v3(c3.y, c3.z, c3.w);
                 const float qa = (Y - sdot(Uw, a)) * c0.w;
                 a = sfma(Swv, qa, a);
-                acur = a;
-                const int sv = (int)((inf >> 16) & 0xffu) - 1;
-                if (NSL > 0 && sv == 0) slot0 = a;
-                if (NSL > 1 && sv == 1) slot1 = a;
+                {
+                    const int sv = (int)((inf >> 16) & 0xffu);      // slot + 1
+                    if (NSL > 0 && sv != 0) {
+                        if (sv == 1) slot0 = a;
+                        else if (NSL > 1) slot1 = a;
+                    }
+                }
                 if (i < 16) XM0[i % clamp16(NMX)] = qa;
                 else if (i < 32) XM1[(i - 16) % clamp16(NMX - 16)] = qa;
                 else if (i < 48) XM2[(i - 32) % clamp16(NMX - 32)] = qa;

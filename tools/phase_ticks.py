@@ -98,6 +98,9 @@ for k in np.unique(wid):
     m = wid == k
     print(f"  wave slot {k}: {int(m.sum())} waves, lifetime mean {total[m].mean() * kc:.1f}k, PGS mean {d[m, 8].mean() * kc:.1f}k, "
           f"before PGS {(tk[m, 8] - tk[m, 0]).mean() * kc:.1f}k")
+if buf[:, 15].any():
+    ov = (buf[:, 15].astype(np.int64) - tk[:, 7]) * kc
+    print(f"  of the impulse responses: overflow rows' path-only response {ov.mean():.2f}k (min {ov.min():.2f}k, max {ov.max():.2f}k)")
 print(f"{'phase':58s} {'mean kclk':>9s} {'min':>7s} {'max':>7s} {'share':>6s}")
 for k, name in enumerate(PHASES):
     c = d[:, k] * kc
