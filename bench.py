@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- NAO env-steps/s at 4096 envs per GPU (BASELINE.json `metric`).
 
+The robot of `value` is the NAO stand-in WITH the 16 finger / thumb joints of its hands (42 dofs, 66 constraint rows),
+the size at which the reference simulates the robot: qibullet's URDF has them as dofs and the reference's envs only keep
+them out of the CONTROLLED joint lists (romeo_env.py:24-26).  The fingers follow LHand / RHand through their <mimic>
+columns, as qibullet's setAngles drives them.  The smaller 26-dof stand-in without finger joints (the headline of
+rounds 1-2) is measured beside it as `nao_without_finger_joints`.
+
 Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): the NAO
 joint-trajectory replay of /root/reference/examples/h5_control_nao.py with the
 `inference.h5` file (not in the reference tree) replaced by a synthetic
@@ -74,7 +80,7 @@ def algorithmic_flops_per_env_step(model, cfg, n_contacts=8, n_substeps=1):
     return n_substeps * (300 * nb + rows * 150 * nb + cfg.solver_iters * rows * 4 * ndof)
 
 
-def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
+def cpu_baseline(model, cfg, rows, sel, target_seconds=float(os.environ.get("HG_BENCH_CPU_SECONDS", "12"))):
     """Oracle (oracle/hg_oracle.c, FP64, OpenMP over envs) on this host, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import OracleSim
@@ -95,6 +101,7 @@ def cpu_baseline(model, cfg, rows, sel, target_seconds=12.0):
            "sample": f"oracle FP64 OpenMP, {n_envs} envs x {steps} steps of the same NAO replay workload"}
     # single thread beside it = BASELINE.json configs[0] (SURVEY 8d "Config 1"): nao-v0, ONE env, random_control
     # (random_control_nao.py:9: action_space.sample() each step = U(lower_j, upper_j), default_rng(0)), 1000 steps;
+    # the same robot model as `value` (configs[0] names nao-v0: here the model with the finger joints);
     # the oracle takes its serial path below four envs
     one = OracleSim(model, cfg, 1)
     idx = np.asarray(model.act_joint)
@@ -172,7 +179,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--robot", default="nao")
+    ap.add_argument("--robot", default="nao_hands", help="nao_hands (default: the NAO at the size the reference simulates), nao (26 dofs, no finger joints), pepper, romeo, romeo_hands, dancer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cfg", action="append", default=[], metavar="KEY=VALUE",
                     help="override a SimConfig field (diagnostics only; the reported metric is the default config)")
@@ -224,8 +231,12 @@ def main():
         k, v = kv.split("=", 1)
         setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
     n_envs = args.envs_per_gpu
-    if args.robot == "nao":
+    is_nao = args.robot in ("nao", "nao_hands")
+    if is_nao:
         rows, sel = synthetic_replay(model)
+        if args.robot == "nao_hands":
+            from humanoid_gym_amd.workloads import nao_replay_joints
+            rows, sel = with_mimic_columns(model, rows, sel, nao_replay_joints())
     else:   # other robots: random targets inside the limits, all controlled joints
         rng = np.random.default_rng(2)
         sel = np.asarray(model.act_joint, np.int32)
@@ -296,6 +307,7 @@ def main():
                               "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "none", "data": "none", "backend": args.backend,
+                              "world_size_seen": (dist.get_world_size() if use_dist else 1),
                               "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms)},
                               "global_env_steps": global_env_steps,
                               "config": {"workload": "dry", "envs_per_gpu": n_envs, "first_env_of_rank0": first_env}}),
@@ -351,16 +363,13 @@ def main():
             pipelined = {"error": f"{type(e).__name__}: {e}"}
     finite = bool(torch.isfinite(sim.get_state()).all().item())
 
-    # Beside the headline as well: the same replay on the NAO stand-in that ALSO simulates the 16 finger joints of the
-    # hands (42 dofs, as qibullet's NAO has; 66 constraint rows = two rows per lane in the kernel), fingers following
-    # LHand / RHand through their mimic columns.
-    with_hands = None
-    if args.robot == "nao" and not args.cfg and world == 1 and os.environ.get("HG_BENCH_HANDS", "1") != "0":
+    # Beside the headline as well: the same replay on the smaller NAO stand-in WITHOUT finger joints (26 dofs, 50
+    # constraint rows), the headline robot of rounds 1-2.
+    without_hands = None
+    if args.robot == "nao_hands" and not args.cfg and world == 1 and os.environ.get("HG_BENCH_SMALL", "1") != "0":
         try:
-            from humanoid_gym_amd.workloads import nao_replay_joints
-            hmodel, hcfg = load_robot("nao_hands")
+            hmodel, hcfg = load_robot("nao")
             hrows, hsel = synthetic_replay(hmodel)
-            hrows, hsel = with_mimic_columns(hmodel, hrows, hsel, nao_replay_joints())
             hsim = HgSim(hmodel, hcfg, n_envs, dev)
             hrows_d = torch.tensor(hrows, device=dev)
             hact = torch.stack([hrows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
@@ -372,14 +381,14 @@ def main():
                 hsim.step(hact[t % T_TRAJ], joint_sel=hsel, n_substeps=1)
             torch.cuda.synchronize()
             h_el = time.perf_counter() - h0
-            with_hands = {"robot": "nao_hands_like (stand-in URDF with the 16 finger joints)", "n_dof": hmodel.n_links,
-                          "constraint_rows": hmodel.n_links + 3 * hcfg.max_contacts, "action_columns": int(len(hsel)),
-                          "value_this_rank": n_envs * args.steps / h_el, "unit": "env-steps/s",
-                          "ms_per_step": h_el / args.steps * 1e3,
-                          "state_finite": bool(torch.isfinite(hsim.get_state()).all().item())}
+            without_hands = {"robot": "nao_like (stand-in URDF without finger joints)", "n_dof": hmodel.n_links,
+                             "constraint_rows": hmodel.n_links + 3 * hcfg.max_contacts, "action_columns": int(len(hsel)),
+                             "value_this_rank": n_envs * args.steps / h_el, "unit": "env-steps/s",
+                             "ms_per_step": h_el / args.steps * 1e3,
+                             "state_finite": bool(torch.isfinite(hsim.get_state()).all().item())}
             hsim.close()
         except Exception as e:      # noqa: BLE001
-            with_hands = {"error": f"{type(e).__name__}: {e}"}
+            without_hands = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         total_envs = n_envs * world
@@ -389,28 +398,30 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside this process, so the figure is the one
         # of the committed rocprofv3 --pmc passes over this same kernel and configuration (named in traffic_source)
         traffic, traffic_source = None, None
-        for cand in ("round2_f_pmc_nao4096.json", "round2_e_pmc_nao4096.json", "round2_c_pmc_nao4096.json", "round2_pmc_nao4096.json", "round1_g_pmc_nao4096.json"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                if args.robot == "nao" and n_envs == 4096 and not args.cfg:
-                    traffic = pm["per_launch"].get("hbm_bytes_corrected", pm.get("hbm_bytes_corrected"))
-                    traffic_source = f"profiles/{cand} (rocprofv3 --pmc passes of this kernel and config, not this run)"
-                    break
-            except Exception:
-                continue
+        pmc_file = {"nao_hands": "round3_pmc_nao_hands4096.json", "nao": "round3_pmc_nao4096.json"}.get(args.robot)
+        try:
+            if pmc_file and n_envs == 4096 and not args.cfg:
+                pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+                traffic = pm["per_launch"].get("hbm_bytes_corrected", pm.get("hbm_bytes_corrected"))
+                traffic_source = f"profiles/{pmc_file} (rocprofv3 --pmc passes of this kernel and config, not this run)"
+        except Exception:
+            traffic, traffic_source = None, None
         ach_gbs = n_envs * bytes_step / (kernel_ms * 1e-3) / 1e9
         ach_tf = n_envs * flops_step / (kernel_ms * 1e-3) / 1e12
         out = {
-            "metric": "NAO env-steps/sec (4096 envs/GPU)" if args.robot == "nao" else f"{args.robot} env-steps/sec",
+            "metric": "NAO env-steps/sec (4096 envs/GPU)" if is_nao else f"{args.robot} env-steps/sec",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms)},
             "global_env_steps": global_env_steps,
+            "backend": (args.backend if use_dist else "none (single process)"),
+            "world_size_seen": (dist.get_world_size() if use_dist else 1),
             "config": {"workload": "NAO h5 joint-trajectory replay (h5_control_nao layout, synthetic sinusoid "
                                    "trajectory), PD position control + ground contact" + (" + link-link contacts" if cfg.enable_self else "") + ", 1 substep of 1/240 s"
-                       if args.robot == "nao" else f"{args.robot} random targets",
-                       "robot": model.name + ("_like (stand-in URDF)" if args.robot != "dancer" else ""),
+                       if is_nao else f"{args.robot} random targets",
+                       "robot": model.name + ("_like (stand-in URDF" + (", with the finger joints of the hands" if args.robot.endswith("_hands") else "") + ")" if args.robot != "dancer" else ""),
+                       "constraint_rows": model.n_links + 3 * cfg.max_contacts, "action_columns": int(len(sel)),
                        "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters,
                        "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -425,9 +436,9 @@ def main():
         }
         if pipelined is not None:
             out["pipelined"] = pipelined
-        if with_hands is not None:
-            out["nao_with_finger_joints"] = with_hands
-        if not args.no_cpu_baseline and world == 1:
+        if without_hands is not None:
+            out["nao_without_finger_joints"] = without_hands
+        if not args.no_cpu_baseline:         # rank 0 only, after the timed region and its closing barrier, for every N
             out["cpu_baseline"] = cpu_baseline(model, cfg, rows, sel)
         print(json.dumps(out), file=json_out, flush=True)
     if use_dist:

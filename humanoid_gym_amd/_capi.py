@@ -24,6 +24,10 @@ SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_res
            "hg_set_base_velocity", "hg_get_joint_torques", "hg_stats_accumulate_noalloc"]
 
 
+# the ABI version that the ctypes mirrors in model.py (HgModel, HgConfig) and the prototypes below are written for
+HG_ABI_VERSION = 6
+
+
 class HgError(RuntimeError):
     pass
 
@@ -38,6 +42,11 @@ def load_library(path: Optional[str] = None):
         raise HgError(f"{p} not found: build it with `python -m humanoid_gym_amd.build` "
                       "(there is no CPU fallback for the simulator)")
     L = C.CDLL(p)
+    L.hg_abi_version.restype = C.c_int
+    L.hg_abi_version.argtypes = []
+    if L.hg_abi_version() != HG_ABI_VERSION:      # a stale in-tree build would read the structs at the wrong strides
+        raise HgError(f"{p} has ABI version {L.hg_abi_version()}, this package needs {HG_ABI_VERSION}: rebuild it "
+                      "(python -m humanoid_gym_amd.build)")
     vp, fp, u8p, i32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
     L.hg_last_error.restype = C.c_char_p
     L.hg_last_error.argtypes = []

@@ -57,7 +57,7 @@ __global__ void reset_kernel(const DevModel *__restrict__ M, float *__restrict__
     if (env >= n_envs || (mask && !mask[env])) return;
     const int n = M->n, S = HG_STATE_SIZE(n);
     float *st = state + (size_t)env * stride;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) torque[(size_t)env * n + k] = 0.f;
+    if (torque) for (int k = threadIdx.x; k < n; k += blockDim.x) torque[(size_t)env * n + k] = 0.f;
     for (int k = threadIdx.x; k < S; k += blockDim.x) {
         float v = 0.f;
         if (k < 3) v = M->base[B_POS0 + k];
@@ -261,6 +261,7 @@ struct hg_sim {
     float *d_torque = nullptr;         // [n_envs][n] applied motor torque of the last physics step
     float *d_base_cmd = nullptr;       // [n_envs][3] commanded base velocity, allocated on first use
     bool base_cmd_on = false;
+    float *d_noalloc_scratch = nullptr; // this device's copy of the static scratch array (hg_stats_accumulate_noalloc)
 };
 
 namespace hg {
@@ -285,7 +286,10 @@ static int check_numbers(const hg_model *m, const hg_config *c, std::string *why
         if (!fin(a, 3) || std::fabs(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] - 1.0) > 1e-3) return bad("joint axis must be a unit vector", i);
         if (!(m->joint_damping[i] >= 0) || !std::isfinite(m->joint_damping[i])) return bad("joint damping must be finite and >= 0", i);
         if (!(m->max_force[i] >= 0) || !(m->max_vel[i] >= 0)) return bad("motor force and velocity bounds must be >= 0 (may be infinite)", i);
-        if (std::isnan(m->lower[i]) || std::isnan(m->upper[i]) || m->lower[i] > m->upper[i]) return bad("joint bounds must satisfy lower <= upper", i);
+        if (std::isnan(m->lower[i]) || std::isnan(m->upper[i])) return bad("joint bounds must not be NaN", i);
+        // (lower > upper on a joint without a limit constraint is the URDF "no limit" convention: nothing to enforce but the
+        //  target clamp, which then needs an ordered interval)
+        if (m->lower[i] > m->upper[i] && (m->joint_limited[i] || c->clamp_targets)) return bad("joint bounds must satisfy lower <= upper where they are used (limit rows, target clamp)", i);
     }
     for (int b = 0; b <= m->n_links; b++)
         if (!fin(m->frame_pos[b], 3) || !fin(m->frame_quat[b], 4)) return bad("URDF frame offsets must be finite", b);
@@ -456,7 +460,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 5; }
+int hg_abi_version(void) { return 6; }
 
 #ifdef HG_PHASE_TIMING
 // diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch (of the variant launched last)
@@ -472,6 +476,12 @@ extern "C" int hg_debug_phase_ticks(unsigned long long *host_out, int n_envs) {
 }
 #endif
 
+// Device address of `scratch` (hg_stats_accumulate_noalloc) on each GPU, resolved by hg_create -- which allocates anyway
+// and has the device current -- so that the entry point itself is a bounds check and two launches (safe under graph
+// capture).  In host code the symbol's name is only a handle for hipGetSymbolAddress, never a pointer a kernel could use.
+static float *g_scratch_ptr[HG_NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
 int hg_create(const hg_model *model, const hg_config *config, int n_envs, int device_id, hg_sim **out) {
     if (!model || !config || !out) return fail(HG_EINVAL, "hg_create: null argument");
     *out = nullptr;
@@ -483,6 +493,8 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
         return fail(HG_EINVAL, "hg_create: model sizes out of range");
     if (config->max_contacts < 0 || config->max_contacts > HG_MAX_CONTACTS || config->solver_iters < 0 || !(config->dt > 0))
         return fail(HG_EINVAL, "hg_create: bad config (max_contacts, solver_iters or dt)");
+    if (config->residual_threshold != 0)       // measured: the exit is not reached within the configured sweeps (profiles/round3_residual_histogram.txt)
+        return fail(HG_EUNSUPPORTED, "hg_create: residual_threshold != 0 is implemented by the CPU oracle only; the HIP solver runs every sweep");
 
     // the model is flattened and matched to a kernel variant on the host first, so an unsupported robot is
     // reported as such with or without a GPU
@@ -533,18 +545,27 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMalloc(&s->d_cum, sizeof(float) * 4 * (size_t)n_envs);
-    if (e == hipSuccess) e = hipMalloc(&s->d_torque, sizeof(float) * (size_t)n_envs * n);
+    if (e == hipSuccess && config->store_torques) e = hipMalloc(&s->d_torque, sizeof(float) * (size_t)n_envs * n);
     if (e == hipSuccess) e = hipMemcpy(s->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
     if (e == hipSuccess) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_cum, 0, sizeof(float) * 4 * (size_t)n_envs);
-    if (e == hipSuccess) e = hipMemset(s->d_torque, 0, sizeof(float) * (size_t)n_envs * n);
+    if (e == hipSuccess && s->d_torque) e = hipMemset(s->d_torque, 0, sizeof(float) * (size_t)n_envs * n);
     delete hm;
     if (e != hipSuccess) {
         const std::string msg = std::string("hg_create: ") + hipGetErrorString(e);
         hg_destroy(s);
         return fail(e == hipErrorOutOfMemory ? HG_ENOMEM : HG_ENODEVICE, msg);
+    }
+    if (device_id < HG_NOALLOC_MAX_DEVICES) {      // this device's copy of the static scratch array (the device is current)
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[device_id]) {
+            void *p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(hg::scratch)) != hipSuccess) { hg_destroy(s); return fail(HG_ENODEVICE, "hg_create: hipGetSymbolAddress(scratch) failed"); }
+            g_scratch_ptr[device_id] = static_cast<float *>(p);
+        }
+        s->d_noalloc_scratch = g_scratch_ptr[device_id];
     }
     rc = hg_reset(s, nullptr, nullptr);
     if (rc == HG_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(HG_ENODEVICE, "hg_create: reset kernel failed");
@@ -646,6 +667,7 @@ int hg_get_joint_states(hg_sim *s, float *q_dev, float *qd_dev, void *stream) {
 int hg_get_joint_torques(hg_sim *s, float *tau_dev, void *stream) {
     if (!s || !tau_dev) return fail(HG_EINVAL, "hg_get_joint_torques: null argument");
     HG_DEVICE(s);
+    if (!s->d_torque) return fail(HG_EINVAL, "hg_get_joint_torques: this handle was created with store_torques = 0");
     HG_HIP(hipMemcpyAsync(tau_dev, s->d_torque, sizeof(float) * (size_t)s->n_envs * s->n, hipMemcpyDeviceToDevice,
                           (hipStream_t)stream));
     return HG_OK;
@@ -716,11 +738,6 @@ int hg_stats_accumulate(hg_sim *s, const float *reward_dev, const uint8_t *done_
     return HG_OK;
 }
 
-// Device address of `scratch` on each GPU, resolved once per device with that device current: in host code the
-// symbol's name is only a handle for hipGetSymbolAddress, never a pointer a kernel could use.
-static float *g_scratch_ptr[HG_NOALLOC_MAX_DEVICES];
-static std::mutex g_scratch_mu;
-
 int hg_stats_accumulate_noalloc(hg_sim *s, const float *reward_dev, const uint8_t *done_dev, const uint8_t *collision_dev,
                                 float *stats_dev, void *stream) {
     if (!s || !stats_dev) return fail(HG_EINVAL, "hg_stats_accumulate_noalloc: null argument");
@@ -730,16 +747,8 @@ int hg_stats_accumulate_noalloc(hg_sim *s, const float *reward_dev, const uint8_
     if (s->device < 0 || s->device >= HG_NOALLOC_MAX_DEVICES)
         return fail(HG_EUNSUPPORTED, "hg_stats_accumulate_noalloc: device index beyond HG_NOALLOC_MAX_DEVICES");
     HG_DEVICE(s);
-    float *part = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (!g_scratch_ptr[s->device]) {
-            void *p = nullptr;
-            HG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(hg::scratch)));      // this device's copy (s->device is current)
-            g_scratch_ptr[s->device] = static_cast<float *>(p);
-        }
-        part = g_scratch_ptr[s->device];
-    }
+    float *const part = s->d_noalloc_scratch;      // resolved once per device by hg_create
+    if (!part) return fail(HG_EUNSUPPORTED, "hg_stats_accumulate_noalloc: no scratch address for this device");
     // Nothing in the array has to start at zero: stage 2 reads exactly the n_slots partials that stage 1 of this
     // call has just written on the same stream; slots beyond them keep an earlier call's contents and are not read.
     const int n_slots = (s->n_envs + NOALLOC_ENVS_PER_SLOT - 1) / NOALLOC_ENVS_PER_SLOT;

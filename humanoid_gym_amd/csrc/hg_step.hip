@@ -478,7 +478,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         Sv pA = ldsv(own + 21);
                         #pragma unroll 1
                         for (int c = fchL[link]; c >= 0; c = nsibL[c]) {
-                            const float *pu = upL + UP * c;
+                            float pu[28];      // the child's record as seven 16-byte LDS reads (UP floats = 112 bytes, 16-byte aligned)
+                            {
+                                const float4 *p4 = reinterpret_cast<const float4 *>(upL + UP * c);
+#pragma unroll
+                                for (int j = 0; j < 7; j++) { const float4 t = p4[j]; pu[4 * j] = t.x; pu[4 * j + 1] = t.y; pu[4 * j + 2] = t.z; pu[4 * j + 3] = t.w; }
+                            }
+                            static_assert(UP == 28, "child -> parent record is seven float4");
                             IA.A.xx += pu[0]; IA.A.xy += pu[1]; IA.A.xz += pu[2]; IA.A.yy += pu[3]; IA.A.yz += pu[4]; IA.A.zz += pu[5];
 #pragma unroll
                             for (int j = 0; j < 9; j++) IA.B.m[j] += pu[6 + j];
@@ -488,7 +494,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         const V3 r = ld3(pc + C_RW);
                         const Sv Sm = ldsv(pc + C_SW);
                         const Sv U = ai_mul(IA, Sm);
-                        const float Dinv = __frcp_rn(sdot(Sm, U));      // v_rcp_f32, 1 ulp
+                        const float Dinv = __builtin_amdgcn_rcpf(sdot(Sm, U));      // v_rcp_f32, 1 ulp (__frcp_rn is a ten-instruction division)
                         const float u = tau0 - sdot(Sm, pA);
                         // the vector this lane pushes through Ia = IA - U U^T / D
                         Sv w;
@@ -941,7 +947,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         }
                     }
                 }
-                const float inv = (R.contact && xdiag > (float)HG_ROW_DEN_EPS) ? __frcp_rn(xdiag) : 0.f;      // else: row disabled
+                const float inv = (R.contact && xdiag > (float)HG_ROW_DEN_EPS) ? __builtin_amdgcn_rcpf(xdiag) : 0.f;      // else: row disabled
 #pragma unroll
                 for (int k = 0; k < NOV; k++) {
                     ov_b[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R.target_err), k));
@@ -1150,7 +1156,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
         for (int k = 0; k < (NOV > 0 ? NOV : 1); k++) AOr[k] = NOV > 0 ? AC[NOV > 0 ? NCL + k : 0] : 0.f;
         {
-            const float dinv = (row_active && diag > (float)HG_ROW_DEN_EPS) ? __frcp_rn(diag) : 0.f;      // else: row disabled (hg_model.h)
+            const float dinv = (row_active && diag > (float)HG_ROW_DEN_EPS) ? __builtin_amdgcn_rcpf(diag) : 0.f;      // else: row disabled (hg_model.h)
             z = target_err * dinv;
 #pragma unroll
             for (int k = 0; k < NMX; k++) {
@@ -1563,7 +1569,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // joint's motor lane, see the one-row-per-lane solver above for the algebra).
         float z1, lo1 = 0.f, hi1 = 0.f;
         {
-            const float dinvB = (R1.contact && diagB > (float)HG_ROW_DEN_EPS) ? __frcp_rn(diagB) : 0.f;
+            const float dinvB = (R1.contact && diagB > (float)HG_ROW_DEN_EPS) ? __builtin_amdgcn_rcpf(diagB) : 0.f;
             z1 = R1.target_err * dinvB;
 #pragma unroll
             for (int k = 0; k < NMX; k++) {
@@ -1706,7 +1712,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         {   // getJointState()[3]: the motor torque applied in this physics step (dancer_env.py:24)
             int lane_t = lane;
             asm volatile("" : "+v"(lane_t));      // fresh address arithmetic
-            if (lane_t < n) O.torque[(size_t)env * n + lane_t] = lam * P.inv_dt;
+            if (O.torque && lane_t < n) O.torque[(size_t)env * n + lane_t] = lam * P.inv_dt;
         }
 
         // ============ 5. velocities += M^-1 J^T lambda =========================================
@@ -1846,7 +1852,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         for (int k = 0; k < 4; k++) bq[k] = M->base[B_QUAT0 + k];
         if (is_link) {
             st[HG_STATE_BASE + lane] = q; st[HG_STATE_BASE + n + lane] = 0.f; st[HG_STATE_BASE + 2 * n + lane] = q;
-            O.torque[(size_t)env * n + lane] = 0.f;
+            if (O.torque) O.torque[(size_t)env * n + lane] = 0.f;
         }
         if (lane == 0) {
             st3(st, bpos); st[3] = bq[0]; st[4] = bq[1]; st[5] = bq[2]; st[6] = bq[3];

@@ -23,10 +23,13 @@ class _SoftbankEnv(BatchedHumanoidEnv):
     ROBOT = ""
 
     def __init__(self, n_envs: int = 1, device=None, urdf_path=None, n_substeps: int = 1,
-                 auto_reset: bool = False, hands: bool = False, **cfg_overrides):
-        """hands=True (nao, romeo): the model with the finger / thumb joints of the hands as simulated dofs, as in
-        qibullet's URDFs (42 / 61 dofs; two constraint rows per lane in the kernel).  They follow LHand / RHand
-        through their <mimic> tags; the controlled joint lists are unchanged (romeo_env.py:24-26)."""
+                 auto_reset: bool = False, hands=None, **cfg_overrides):
+        """hands (nao, romeo; default True): the model with the finger / thumb joints of the hands as simulated dofs, as
+        the robots that the reference steps have them -- romeo_env.py:24-26 filters `Finger` / `Thumb` out of the
+        CONTROLLED list only (42 / 61 dofs).  They follow LHand / RHand through their <mimic> tags; the controlled
+        joint lists are unchanged.  hands=False: the smaller stand-ins without finger joints (26 / 37 dofs)."""
+        if hands is None:
+            hands = self.ROBOT in ("nao", "romeo") and urdf_path is None
         model, cfg = load_robot(self.ROBOT, urdf_path, hands=hands)
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)

@@ -87,6 +87,9 @@ class HgConfig(C.Structure):
         ("clamp_targets", C.c_int32),
         ("enable_limits", C.c_int32),
         ("limit_max_impulse", C.c_double),
+        ("residual_threshold", C.c_double),
+        ("store_torques", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -113,6 +116,9 @@ class SimConfig:
     clamp_targets: bool = True
     enable_limits: bool = True           # btMultiBodyJointLimitConstraint rows for revolute joints
     limit_max_impulse: float = 100.0     # btMultiBodyConstraint m_maxAppliedImpulse [UPSTREAM-RECALL]
+    residual_threshold: float = 0.0      # > 0: leave the sweep loop once a sweep's largest squared velocity residual is <= this
+                                         # (PyBullet's solverResidualThreshold default is 1e-7 [UPSTREAM-RECALL]); 0: every sweep
+    store_torques: bool = True           # keep the applied motor torques of each physics step for joint_torques()
 
     def to_c(self) -> HgConfig:
         c = HgConfig()
@@ -131,6 +137,8 @@ class SimConfig:
         c.clamp_targets = int(self.clamp_targets)
         c.enable_limits = int(self.enable_limits)
         c.limit_max_impulse = self.limit_max_impulse
+        c.residual_threshold = float(self.residual_threshold)
+        c.store_torques = int(self.store_torques)
         return c
 
 

@@ -227,6 +227,7 @@ def load_urdf(path: str,
               base_position: Sequence[float] = (0, 0, 0),
               base_orientation: Sequence[float] = (0, 0, 0, 1),
               self_collision: bool = False,
+              self_exclude: str = "all_parents",
               default_max_force: float = 100000.0,
               default_max_vel: float = BIG,
               mesh_aabbs: Optional[Dict[str, Tuple[Sequence[float], Sequence[float]]]] = None,
@@ -236,7 +237,10 @@ def load_urdf(path: str,
 
     ``base_position`` / ``base_orientation`` place the root LINK frame, as the
     ``basePosition`` / ``baseOrientation`` arguments of ``loadURDF`` do
-    (dancer_env.py:59).  ``mesh_aabbs`` supplies link-frame bounds for mesh
+    (dancer_env.py:59).  ``self_collision`` builds the link-link pair table; ``self_exclude`` says which pairs never
+    collide: "all_parents" = a link and any of its ancestors (URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, what the
+    reference passes for Dancer, dancer_env.py:60), "parent" = a link and its direct parent only (plain
+    URDF_USE_SELF_COLLISION, what qibullet is recalled to pass [UPSTREAM-RECALL]).  ``mesh_aabbs`` supplies link-frame bounds for mesh
     geometry whose files are not on disk.
     """
     root = ET.parse(path).getroot()
@@ -384,7 +388,8 @@ def load_urdf(path: str,
         dvec[k] = RLp.T @ (tj - body_com[pb + 1])
         evec[k] = RLc.T @ body_com[k + 1]
         damping[k] = j["damping"]
-        if j["type"] == "continuous" or j["lower"] is None:
+        if j["type"] == "continuous" or j["lower"] is None or j["lower"] > j["upper"]:
+            # (lower > upper is the common "no limit" convention: Bullet loads such a joint and adds no limit constraint)
             lower[k], upper[k] = -math.pi, math.pi   # dancer_env.py:80-81
         else:
             lower[k], upper[k] = j["lower"], j["upper"]
@@ -451,6 +456,8 @@ def load_urdf(path: str,
     # self-collision pairs: different bodies, neither an ancestor of the other
     # (URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, dancer_env.py:60)
     pair_a, pair_b = [], []
+    if self_exclude not in ("all_parents", "parent"):
+        raise ValueError(f"self_exclude must be 'all_parents' or 'parent', not {self_exclude!r}")
     if self_collision:
         anc = [set() for _ in range(n)]
         for k in range(n):
@@ -465,7 +472,12 @@ def load_urdf(path: str,
                 if not (s_flag[b2] & SPHERE_SELF) or s_link[b2] < 0:
                     continue
                 la, lb = s_link[a], s_link[b2]
-                if la == lb or la in anc[lb] or lb in anc[la]:
+                if la == lb:
+                    continue
+                if self_exclude == "all_parents":
+                    if la in anc[lb] or lb in anc[la]:
+                        continue
+                elif parent[la] == lb or parent[lb] == la:
                     continue
                 pair_a.append(a)
                 pair_b.append(b2)

@@ -113,6 +113,13 @@ typedef struct hg_config {
     int32_t clamp_targets;     /* qibullet setAngles clamps to the limits             */
     int32_t enable_limits;     /* joint-limit constraint rows for joint_limited joints */
     double  limit_max_impulse; /* btMultiBodyConstraint m_maxAppliedImpulse, 100      */
+    double  residual_threshold;/* > 0: the solver leaves its sweep loop after the first sweep whose largest squared
+                                  velocity residual (impulse change x J M^-1 J^T of the row) is <= this, as Bullet's
+                                  m_leastSquaresResidualThreshold does (PyBullet sets 1e-7 [UPSTREAM-RECALL]; the
+                                  reference sets only the iteration count, dancer_env.py:64).  0: all solver_iters sweeps */
+    int32_t store_torques;     /* 1: the applied motor torques of every physics step are kept for hg_get_joint_torques
+                                  (getJointState()[3], dancer_env.py:24); 0: not stored, the getter fails             */
+    int32_t reserved0;
 } hg_config;
 
 /* State record of one env: HG_STATE_BASE + 3*n values (double in the oracle,

@@ -477,11 +477,13 @@ typedef struct {
  * update of such a row are 0, its impulse stays 0 */
 static double row_diag_inv(double den) { return den > HG_ROW_DEN_EPS ? 1.0 / den : 0.0; }
 
-static void resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int ndof) {
+/* Returns the velocity residual of the update, deltaImpulse / m_jacDiagABInv as
+ * btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric does [UPSTREAM-RECALL]. */
+static double resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int ndof) {
     double lo = r->lo, hi = r->hi;
     if (r->normal_row >= 0) {
         const double tot = rows[r->normal_row].lambda;
-        if (!(tot > 0)) return;
+        if (!(tot > 0)) return 0.0;
         lo = -mu * tot; hi = mu * tot;
     }
     double jv = 0;
@@ -494,7 +496,15 @@ static void resolve_row(row_t *r, const row_t *rows, double mu, double *dv, int 
     dl = sum - r->lambda;
     r->lambda = sum;
     for (int k = 0; k < ndof; k++) dv[k] += r->u[k] * dl;
+    return r->diag_inv > 0 ? dl / r->diag_inv : 0.0;
 }
+
+/* Test instrumentation (tools/residual_histogram.py): with a probe threshold set, every physics step records the first
+ * sweep after which the largest squared residual was <= probe (solver_iters + 1: never), whatever the config says. */
+static double hgo_probe_threshold = 0.0;
+static long hgo_sweep_hist[1026];
+void hgo_residual_probe(double threshold) { hgo_probe_threshold = threshold; memset(hgo_sweep_hist, 0, sizeof hgo_sweep_hist); }
+void hgo_residual_histogram(long *out, int n) { for (int k = 0; k < n && k < 1026; k++) out[k] = hgo_sweep_hist[k]; }
 
 typedef struct {
     int n_contacts;
@@ -614,13 +624,25 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
     }
 
     memset(dv, 0, sizeof(double) * ndof);
+    /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations [UPSTREAM-RECALL]: the residual of a sweep is
+     * the largest squared velocity residual of its row updates; the loop ends after the first sweep with
+     * residual <= m_leastSquaresResidualThreshold (config residual_threshold; 0 = run every sweep). */
+    int first_below = -1;
     for (int it = 0; it < c->solver_iters; it++) {
+        double lsr = 0.0, rr;
         for (int j = 0; j < n_noncontact; j++) {
             const int idx = (it & 1) ? j : n_noncontact - 1 - j;
-            resolve_row(&rows[idx], rows, c->friction, dv, ndof);
+            rr = resolve_row(&rows[idx], rows, c->friction, dv, ndof); if (rr * rr > lsr) lsr = rr * rr;
         }
-        for (int j = first_normal; j < first_friction; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
-        for (int j = first_friction; j < nr; j++) resolve_row(&rows[j], rows, c->friction, dv, ndof);
+        for (int j = first_normal; j < first_friction; j++) { rr = resolve_row(&rows[j], rows, c->friction, dv, ndof); if (rr * rr > lsr) lsr = rr * rr; }
+        for (int j = first_friction; j < nr; j++) { rr = resolve_row(&rows[j], rows, c->friction, dv, ndof); if (rr * rr > lsr) lsr = rr * rr; }
+        if (hgo_probe_threshold > 0 && first_below < 0 && lsr <= hgo_probe_threshold) first_below = it + 1;
+        if (c->residual_threshold > 0 && lsr <= c->residual_threshold) break;
+    }
+    if (hgo_probe_threshold > 0) {
+        const int slot = first_below < 0 ? (c->solver_iters + 1 > 1025 ? 1025 : c->solver_iters + 1) : (first_below > 1025 ? 1025 : first_below);
+#pragma omp atomic
+        hgo_sweep_hist[slot]++;
     }
 
     HGO_FLOPS(ndof + 2 * (3 + n) + 60);    /* v += dv, positions, quaternion update */

@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_capi.SYMBOLS)
     for n in names:
         assert getattr(L, n) is not None
-    assert L.hg_abi_version() == 5
+    from humanoid_gym_amd._capi import HG_ABI_VERSION
+    assert L.hg_abi_version() == HG_ABI_VERSION == 6
 
 
 def test_struct_sizes_match_header():
@@ -163,6 +164,7 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["backend"] == "gloo"
+    assert rec["world_size_seen"] == 2                                # what torch.distributed itself reports
     assert rec["global_env_steps"] == 2 * 64 * (3 + 1)              # both ranks' envs went through the all-reduce
     assert rec["per_rank_ms_per_step"]["min"] <= rec["per_rank_ms_per_step"]["max"]
     assert "DRY RUN" in rec["metric"] and rec["value"] == 0.0        # never mistaken for a measurement
@@ -185,7 +187,7 @@ def test_reference_robot_kernel_variants_use_no_scratch():
         pytest.skip("kernel_resources.json is written by humanoid_gym_amd.build.build(); library not built from these sources")
     res = json.load(open(hb.RESOURCES))
     expect = {"dancer": ("<18,12,6,0,4>", 4), "nao": ("<26,8,6,0,4>", 4), "pepper": ("<20,8,9,2,4>", 4),
-              "romeo": ("<37,8,12,2,3>", 3), "nao_hands": ("<44,8,12,2,2>", 2)}
+              "romeo": ("<37,8,12,2,3>", 3), "nao_hands": ("<42,8,12,2,3>", 3)}
     for robot, (variant, waves) in expect.items():
         model, cfg = load_robot(robot)
         nmx, maxc = (int(x) for x in variant.strip("<>").split(",")[:2])

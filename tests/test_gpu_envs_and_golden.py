@@ -126,7 +126,13 @@ def test_nao_pepper_romeo_env_surfaces():
     rom = hg.make("romeo-v0", n_envs=4)
     o, r, d, i = rom.step(torch.tensor(np.tile(rom.init_angles, (4, 1)), dtype=torch.float32, device="cuda:0"))
     assert tuple(o["anglesPosition"].shape) == (4, 37) and tuple(o["position"].shape) == (4, 3)
-    for e in (nao, nao1, pep, rom):
+    # the robots are simulated at the size the reference simulates them: finger / thumb joints are dofs of the model
+    # (romeo_env.py:24-26 keeps them out of the CONTROLLED list only); hands=False is the opt-out
+    assert nao.model.n_links == 42 and rom.model.n_links == 61 and pep.model.n_links == 20
+    assert all("Finger" not in j and "Thumb" not in j for j in rom.joint_names)
+    small = hg.make("nao-v0", n_envs=2, hands=False)
+    assert small.model.n_links == 26 and small.joint_names == nao.joint_names
+    for e in (nao, nao1, pep, rom, small):
         e.close()
 
 
@@ -194,9 +200,11 @@ def test_batched_custom_reward_and_auto_reset():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,n_envs,n_substeps", [("pepper", 16384, 1), ("romeo", 8192, 1), ("dancer", 65536, 4)])
+@pytest.mark.parametrize("name,n_envs,n_substeps", [("pepper", 16384, 1), ("romeo", 8192, 1), ("dancer", 65536, 4),
+                                                    ("nao_hands", 4096, 1), ("romeo_hands", 8192, 1)])
 def test_full_size_invariants_other_configs(name, n_envs, n_substeps):
-    """BASELINE.json configs 3-5 at their per-GPU sizes, through size-independent properties: two
+    """BASELINE.json configs 3-5 at their per-GPU sizes (and configs 2 / 4 on the models with finger joints, the size
+    the reference simulates), through size-independent properties: two
     launches from the same state give bit-identical results (no race, no dependence on scheduling),
     envs with equal inputs stay bit-identical wherever they sit in the batch, everything stays finite."""
     model, cfg, sim, torch = _sim(name, n_envs)
@@ -419,9 +427,9 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     import sys
     root = os.path.dirname(HERE)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(HG_BENCH_SINGLE_DEVICE="1", HG_BENCH_HANDS="0", HG_STATS_EVERY="4")
+    env.update(HG_BENCH_SINGLE_DEVICE="1", HG_BENCH_SMALL="0", HG_STATS_EVERY="4", OMP_NUM_THREADS="4", HG_BENCH_CPU_SECONDS="2")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "12",
-                          "--warmup", "4", "--envs-per-gpu", "256", "--no-cpu-baseline", "--stream-groups", "0"],
+                          "--warmup", "4", "--envs-per-gpu", "256", "--stream-groups", "0"],
                          env=env, capture_output=True, text=True, timeout=170)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -430,6 +438,9 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     assert rec["n_gpus"] == 2 and rec["config"]["envs_per_gpu"] == 256 and rec["config"]["state_finite"]
     assert rec["global_env_steps"] == 2 * 256 * (12 + 4)            # both ranks' counters arrived through the all-reduce
     assert rec["value"] > 0 and rec["per_rank_ms_per_step"]["max"] >= rec["per_rank_ms_per_step"]["min"] > 0
+    # the N > 1 line is complete: backend and world size as torch.distributed saw them, the CPU baseline (rank 0), the roofline
+    assert rec["backend"] == "gloo" and rec["world_size_seen"] == 2 and rec["config"]["n_dof"] == 42
+    assert rec["cpu_baseline"]["value"] > 0 and rec["roofline"]["achieved"] > 0
 
 
 def test_example_drivers_run(capsys):
