@@ -1,6 +1,7 @@
 """Minimal driver for rocprofv3 passes: N launches of hg_step on one robot/config.
 usage: python tools/prof_step.py <robot> <n_envs> <launches> [n_substeps] [random] [cfg_key=value ...]
-`random`: new uniform targets inside the joint limits every 10 launches (random_control_*.py) instead of holding the reset targets."""
+`random`: new uniform targets inside the joint limits every 10 launches (random_control_*.py) instead of holding the reset targets.
+`replay` (nao, nao_hands): the bench workload -- the h5-layout trajectory replay (+ the fingers' mimic columns), every env at its own frame."""
 import ast, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +16,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 rest = sys.argv[4:]
 sub = int(rest.pop(0)) if rest and rest[0].isdigit() else 1
 rand = bool(rest and rest[0] == "random")
-if rand:
+replay = bool(rest and rest[0] == "replay")
+if rand or replay:
     rest.pop(0)
 model, cfg = load_robot(robot)
 for kv in rest:
@@ -24,6 +26,17 @@ for kv in rest:
 sim = HgSim(model, cfg, n_envs, "cuda:0")
 rng = np.random.default_rng(4)
 acts = None
+if replay:
+    import bench
+    from humanoid_gym_amd.workloads import nao_replay_joints
+    rows, sel = bench.synthetic_replay(model)
+    if robot == "nao_hands":
+        rows, sel = bench.with_mimic_columns(model, rows, sel, nao_replay_joints())
+    rows_d = torch.tensor(rows, device="cuda:0")
+    phase = torch.arange(n_envs, device="cuda:0") % bench.T_TRAJ
+    for t in range(reps):
+        sim.step(rows_d[(t + phase) % bench.T_TRAJ].contiguous(), joint_sel=sel, n_substeps=sub)
+    reps = 0
 for t in range(reps):
     if rand and t % 10 == 0:
         a = rng.uniform(-1, 1, (n_envs, 18)).astype(np.float32) if robot == "dancer" else random_actions(model, rng, n_envs)
