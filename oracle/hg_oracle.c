@@ -404,6 +404,28 @@ static void plane_space(const double n[3], double p[3], double q[3]) {
     }
 }
 
+/* Test instrumentation (tests/_oracle.py: OracleSim.noise_spread): "what would an FP32 implementation of this same step
+ * answer?"  With eps > 0 every constraint row is perturbed before the sweeps -- each entry of its impulse response
+ * M^-1 J^T, its right-hand side and its diagonal by an independent relative error of standard deviation eps -- which is
+ * what the roundings of a float32 ABA / Jacobian chain leave in those numbers (eps ~ 1e-6 = 16 ulp) -- and every
+ * collision sphere's world centre is moved by eps * 0.3 m per coordinate (3e-7 m: float32 positions of O(1 m) after a
+ * chain of transforms), which reaches contact points, normals, distances and through them the tangent basis.  The noise stream
+ * of env e is seeded with (seed, e), so a batch of identical envs samples the spread of the answer. */
+static double hgo_noise_eps = 0.0;
+static uint64_t hgo_noise_seed = 0;
+static _Thread_local uint64_t hgo_rng_state;
+void hgo_set_row_noise(double eps, uint64_t seed) { hgo_noise_eps = eps; hgo_noise_seed = seed; }
+static void noise_begin(int env) {
+    hgo_rng_state = (hgo_noise_seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)(env + 1) * 0xD1B54A32D192ED03ull;
+}
+static double noise_factor(void) {       /* 1 + eps * u, u uniform with unit variance */
+    uint64_t x = hgo_rng_state;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    hgo_rng_state = x;
+    const double u01 = (double)((x * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+    return 1.0 + hgo_noise_eps * 3.4641016151377544 * (u01 - 0.5);
+}
+
 /* ------------------------------------------------------------------ */
 /* contact detection                                                   */
 /* ------------------------------------------------------------------ */
@@ -423,6 +445,7 @@ static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_
         m3_mulv(w->Rw[b], m->sphere_pos[s], t);
         HGO_FLOPS(4);
         for (int k = 0; k < 3; k++) cw[s][k] = w->xw[b][k] + t[k];
+        if (hgo_noise_eps > 0) for (int k = 0; k < 3; k++) cw[s][k] += 0.3 * (noise_factor() - 1.0);
         dist[s] = cw[s][2] - m->sphere_radius[s];
     }
     if (c->enable_ground) {
@@ -505,6 +528,8 @@ static double hgo_probe_threshold = 0.0;
 static long hgo_sweep_hist[1026];
 void hgo_residual_probe(double threshold) { hgo_probe_threshold = threshold; memset(hgo_sweep_hist, 0, sizeof hgo_sweep_hist); }
 void hgo_residual_histogram(long *out, int n) { for (int k = 0; k < n && k < 1026; k++) out[k] = hgo_sweep_hist[k]; }
+
+
 
 typedef struct {
     int n_contacts;
@@ -623,6 +648,11 @@ static int physics_step(const hg_model *m, const hg_config *c, double *st, step_
         }
     }
 
+    if (hgo_noise_eps > 0)
+        for (int j = 0; j < nr; j++) {
+            for (int k = 0; k < ndof; k++) rows[j].u[k] *= noise_factor();
+            rows[j].rhs *= noise_factor(); rows[j].diag_inv *= noise_factor();
+        }
     memset(dv, 0, sizeof(double) * ndof);
     /* btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations [UPSTREAM-RECALL]: the residual of a sweep is
      * the largest squared velocity residual of its row updates; the loop ends after the first sweep with
@@ -761,6 +791,7 @@ int hgo_step_full(const hg_model *m, const hg_config *c, int n_envs, double *sta
         double *q = st + HG_STATE_BASE, *qd = q + n, *tgt = qd + n;
         step_info_t info;
         memset(&info, 0, sizeof info);
+        if (hgo_noise_eps > 0) noise_begin(e);
         if (actions)
             for (int k = 0; k < n_sel; k++) {
                 const int j = joint_sel[k];

@@ -60,6 +60,8 @@ def lib():
         L.hgo_contact_slack.restype = None
         L.hgo_kinematics.argtypes = [C.POINTER(HgModel), dp, dp, dp]
         L.hgo_kinematics.restype = None
+        L.hgo_set_row_noise.argtypes = [C.c_double, C.c_uint64]
+        L.hgo_set_row_noise.restype = None
         _LIB = L
     return _LIB
 
@@ -166,6 +168,35 @@ class OracleSim:
             raise RuntimeError(f"hgo_step failed: {rc}")
         return dict(q=obs_q, qd=obs_qd, base_xyyaw=xyyaw, collision=col, link_mask=mask,
                     pairs=pairs, n_contacts=nc, motor_torque=tau)
+
+    def noise_spread(self, state_row, action_row=None, joint_sel=None, n_substeps=1, base_cmd_row=None, trials=64,
+                     eps=1e-6, seed=0):
+        """How far does the oracle's OWN answer for one sample move when its constraint rows carry the rounding errors
+        of a float32 implementation?  `trials` copies of the sample are stepped with independent relative noise of
+        standard deviation `eps` on every entry of every row's impulse response, right-hand side and diagonal
+        (hgo_set_row_noise), plus one clean copy.  Returns the largest deviations from the clean answer:
+        dict(q, qd, tau_rel, base) -- joint angles [rad], joint rates [rad/s], motor torques relative to
+        max(1, largest clean torque), base x / y / yaw.  A kernel-oracle difference that is not larger than a small
+        multiple of this is a property of the sample (a degenerate row set), not of the kernel."""
+        sim = OracleSim(self.model, self.cfg, trials + 1)
+        sim.state[:] = np.asarray(state_row, np.float64)[None, :]
+        act = None if action_row is None else np.repeat(np.asarray(action_row, np.float64)[None, :], trials + 1, axis=0)
+        cmd = None if base_cmd_row is None else np.repeat(np.asarray(base_cmd_row, np.float64)[None, :], trials + 1, axis=0)
+        clean = OracleSim(self.model, self.cfg, 1)
+        clean.state[:] = sim.state[:1]
+        oc = clean.step(None if act is None else act[:1], joint_sel=joint_sel, n_substeps=n_substeps,
+                        base_cmd=None if cmd is None else cmd[:1])
+        lib().hgo_set_row_noise(float(eps), int(seed))
+        try:
+            o = sim.step(act, joint_sel=joint_sel, n_substeps=n_substeps, base_cmd=cmd)
+        finally:
+            lib().hgo_set_row_noise(0.0, 0)
+        tscale = max(1.0, float(np.abs(oc["motor_torque"][0]).max()))
+        dxy = o["base_xyyaw"] - oc["base_xyyaw"][0]
+        dxy[:, 2] = (dxy[:, 2] + np.pi) % (2 * np.pi) - np.pi
+        return dict(q=float(np.abs(sim.q - clean.q[0]).max()), qd=float(np.abs(sim.qd - clean.qd[0]).max()),
+                    tau_rel=float(np.abs(o["motor_torque"] - oc["motor_torque"][0]).max()) / tscale,
+                    base=float(np.abs(dxy).max()), same_contacts=bool((o["n_contacts"] == oc["n_contacts"][0]).all()))
 
     def link_states(self):
         nb = self.n + 1

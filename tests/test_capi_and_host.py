@@ -198,21 +198,30 @@ def test_reference_robot_kernel_variants_use_no_scratch():
 
 
 def test_parity_bookkeeping_helpers():
-    """The helpers the GPU parity tests lean on, exercised on the CPU: FloatParity lets a few contact samples be
-    outliers (bounded, counted) and nothing else; IntParity accepts a different contact set only with margin slack."""
-    from test_gpu_parity import FloatParity, IntParity, SLACK_TOL
+    """The helpers the GPU parity tests lean on, exercised on the CPU: FloatParity accepts a contact sample beyond the
+    tolerance only when the oracle's own spread under float32-sized row noise explains it (bounded, counted), and
+    nothing else; IntParity accepts a different contact set only with margin slack."""
+    from test_gpu_parity import FloatParity, IntParity, SLACK_TOL, EXPLAIN_FACTOR
+    wide = dict(q=1e-3, base=0.0, qd=0.2, tau_rel=0.1)           # an oracle answer that jumps under row noise
+    steady = dict(q=4e-7, base=1e-7, qd=1e-4, tau_rel=1e-5)      # an ordinary sample
     fp = FloatParity(1e-4, 0.03)
     for _ in range(300):
         fp.add(4, 2e-6, 1e-3)
-    fp.add(12, 3e-3, 0.5)                    # one degenerate contact sample
-    fp.report("unit")                        # 1 <= max(1, ceil(0.004 * 301)) = 2
-    fp.add(7, 2e-3); fp.add(7, 2e-3)
+    fp.add(12, 3e-3, 0.5, spread=wide)       # one degenerate contact sample, explained
+    fp.report("unit")                        # 1 <= max(1, ceil(0.003 * 301)) = 1
+    fp.add(7, 2e-3, spread=wide)
     with pytest.raises(AssertionError):
-        fp.report("unit")                    # three outliers among 303 contact samples
+        fp.report("unit")                    # two explained outliers among 302 contact samples: one too many
     with pytest.raises(AssertionError):
-        FloatParity(1e-4).add(0, 2e-4)       # a contact-free sample may never be an outlier
+        FloatParity(1e-4).add(3, 5e-4, spread=steady)      # beyond the tolerance and NOT explained: this is what a kernel bug looks like
     with pytest.raises(AssertionError):
-        FloatParity(1e-4).add(3, 0.5)        # beyond the bound
+        FloatParity(1e-4).add(3, 1.01 * EXPLAIN_FACTOR * 1e-3, spread=wide)      # further off than the spread explains
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(3, 5e-4)       # an outlier with nothing to explain it by
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(0, 2e-4, spread=wide)       # a contact-free sample may never be an outlier
+    with pytest.raises(AssertionError):
+        FloatParity(1e-4).add(3, 0.5, spread=wide)        # beyond the bound
     with pytest.raises(AssertionError):
         FloatParity(1e-4).add(3, float("nan"))
 

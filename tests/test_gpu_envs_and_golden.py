@@ -54,14 +54,14 @@ def test_golden_nao_replay_ground_and_dancer_random():
     for t in range(T):
         sim.set_state(torch.tensor(z["state"][t]))
         cpu.state[:] = z["state"][t]
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, z["actions"][t])
         q = sim.step(torch.tensor(z["actions"][t], device="cuda:0"))[0].cpu().numpy()
         pairs, counts, mask = sim.contact_pairs()
         pairs, counts, mask = pairs.cpu().numpy(), counts.cpu().numpy(), mask.cpu().numpy().astype(np.uint64)
         o = dict(n_contacts=z["n_contacts"][t], pairs=z["pairs"][t], link_mask=z["link_mask"][t])
         for e in range(2):
             if ip.check(e, o, counts, pairs, mask):
-                fp.add(o["n_contacts"][e], float(np.abs(q[e] - z["q"][t][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(q[e] - z["q"][t][e]).max()), env=e)
     ip.report("golden dancer")
     fp.report("golden dancer")
     assert z["n_contacts"].max() >= 4 and (z["pairs"][..., 1] >= -1).any()      # the fixture does hold ground and link-link contacts

@@ -82,7 +82,7 @@ def test_hands_one_step_parity_from_shared_states(name, steps, cfg_kw):
             act = rng.uniform(lo, hi, (n_envs, n)).astype(np.float32).astype(np.float64)
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, act, joint_sel=sel)
         o = cpu.step(act, joint_sel=sel)
         gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel)
         pairs, counts, mask = gpu.contact_pairs()
@@ -98,7 +98,7 @@ def test_hands_one_step_parity_from_shared_states(name, steps, cfg_kw):
                 before = len(fp.outliers)
                 fp.add(o["n_contacts"][e], float(np.abs(st[e, 13:13 + n] - cpu.q[e]).max()),
                        float(np.abs(st[e, 13 + n:13 + 2 * n] - cpu.qd[e]).max()),
-                       float(np.abs(tau[e] - o["motor_torque"][e]).max()) / scale)
+                       float(np.abs(tau[e] - o["motor_torque"][e]).max()) / scale, env=e)
                 if len(fp.outliers) == before:
                     assert np.abs(st[e, :3] - cpu.state[e, :3]).max() < 1e-4
     ip.report(f"{name} {cfg_kw}")
@@ -173,7 +173,7 @@ def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
             act = rng.uniform(-1.0, 1.0, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, act)
         o = cpu.step(act)
         gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
         pairs, counts, mask = gpu.contact_pairs()
@@ -181,7 +181,7 @@ def test_large_random_trees_one_step_parity(gen, over, steps, tmp_path):
         contacts += int(o["n_contacts"].sum())
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask):
-                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()), env=e)
     ip.report(f"large tree {gen['n_links']} links")
     fp.report(f"large tree {gen['n_links']} links")
     assert contacts > 0
@@ -255,7 +255,7 @@ def test_every_kernel_instantiation_agrees_with_the_oracle(robot, variant, cfg_k
             act = rng.uniform(lo, hi, (n_envs, len(idx))).astype(np.float32).astype(np.float64)
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, act)
         o = cpu.step(act)
         gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
         pairs, counts, mask = gpu.contact_pairs()
@@ -263,7 +263,7 @@ def test_every_kernel_instantiation_agrees_with_the_oracle(robot, variant, cfg_k
         contacts += int(o["n_contacts"].sum())
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask):
-                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()), env=e)
     ip.report(f"{robot} on variant {variant}")
     fp.report(f"{robot} on variant {variant}")
     assert contacts > 0

@@ -67,22 +67,41 @@ class IntParity:
 # One-step float comparison under CONTACT.  A fixed number of Gauss-Seidel sweeps over a degenerate row set -- several
 # contact rows between one pair of links, friction rows whose bounds follow a normal impulse that sits at 0, 1e5 N m
 # motors pressing interpenetrating links together -- is not a continuous function of its rounding errors: a few
-# samples in 10^4 come out O(1e-3 .. 1e-1) rad away from the FP64 result, in ANY FP32 formulation and at different
-# states for each (profiles/round2_d_one_step_outliers.txt, tools/one_step_stats.py: of 76 800 Dancer samples per
-# run 17 - 21 are beyond 1e-4 rad in either of two formulations of the kernel, 1 in 34 000 of those without a
-# link-link contact, none for NAO / Romeo beyond 2.4e-4; the builds share only the states at which the FP64 oracle
-# is itself discontinuous).  So: every
-# contact-free sample within `tol`; of the samples with contacts all but max(1, 0.4 %) within `tol`, and those
-# few bounded by `bound`.  A wrong kernel fails this at once (every sample is off), a degenerate state does not.
+# samples in 10^5 come out O(1e-3) rad away from the FP64 result in ANY FP32 formulation.  Such a sample is accepted
+# only if it is EXPLAINED (as IntParity does for the integers): the oracle is asked how far its own
+# answer for that very sample moves when its constraint rows carry float32-sized rounding errors (OracleSim.noise_spread:
+# 256 trials, every entry of every row's impulse response, right-hand side and diagonal perturbed by 1e-6 relative), and
+# the kernel's difference must lie within EXPLAIN_FACTOR times that spread, quantity by quantity.  Everything else --
+# every contact-free sample, every sample whose oracle answer is steady -- must be within `tol`; explained samples are
+# bounded by `bound` and capped at max(1, 0.3 %) of the samples with contacts (the worst case of the suite: a random
+# 45-link tree that two interpenetrating boxes fling about, 2 of 890).
+EXPLAIN_FACTOR = 6.0
+EXPLAIN_TRIALS = 256
+EXPLAIN_EPS = 1e-6
+
+
 class FloatParity:
-    def __init__(self, tol_q, tol_qd=None, tol_tau=None, bound=0.2):
+    def __init__(self, tol_q, tol_qd=None, tol_tau=None, bound=0.05):
         self.tol = (tol_q, tol_qd, tol_tau)
         self.bound = bound
         self.n = self.n_contact = 0
         self.worst = [0.0, 0.0, 0.0]          # over the samples within tolerance
-        self.outliers = []
+        self.outliers = []                     # explained ones: (n_contacts, |dq|)
+        self.spreads = []                      # their oracle spreads (q, qd, tau)
+        self._ctx = None
 
-    def add(self, n_contacts, dq, dqd=None, dtau=None):
+    def pre(self, cpu, act=None, joint_sel=None, n_substeps=1, base_cmd=None):
+        """call with the shared state BEFORE stepping: what an outlier's explanation re-runs the oracle on."""
+        self._ctx = (cpu, cpu.state.copy(), None if act is None else np.array(act, np.float64), joint_sel, n_substeps,
+                     None if base_cmd is None else np.array(base_cmd, np.float64))
+
+    def explain(self, e):
+        cpu, before, act, sel, n_sub, cmd = self._ctx
+        return cpu.noise_spread(before[e], None if act is None else act[e], joint_sel=sel, n_substeps=n_sub,
+                                base_cmd_row=None if cmd is None else cmd[e], trials=EXPLAIN_TRIALS, eps=EXPLAIN_EPS)
+
+    def add(self, n_contacts, dq, dqd=None, dtau=None, env=None, spread=None):
+        """env: index of the sample in the state given to pre() (needed to explain an outlier); or `spread` directly."""
         self.n += 1
         self.n_contact += 1 if n_contacts > 0 else 0
         vals = (dq, dqd, dtau)
@@ -90,18 +109,28 @@ class FloatParity:
         if bad:
             assert n_contacts > 0, f"contact-free sample outside the tolerance: {vals} vs {self.tol}"
             assert np.isfinite(dq) and dq < self.bound, f"outlier beyond the bound: |dq| = {dq}"
+            if spread is None:
+                assert env is not None and self._ctx is not None, f"outlier {vals} with nothing to explain it by (call pre(), pass env=)"
+                spread = self.explain(env)
+            sp = (max(spread["q"], spread["base"]), spread["qd"], spread["tau_rel"])
+            for v, t, s_ in zip(vals, self.tol, sp):
+                if v is not None and t is not None and not (v < t):
+                    assert v <= EXPLAIN_FACTOR * s_, (
+                        f"UNEXPLAINED outlier: kernel - oracle = {vals} (tolerances {self.tol}), {n_contacts} contacts, but the "
+                        f"oracle's own answer moves only by {sp} under float32-sized row noise ({EXPLAIN_TRIALS} trials)")
             self.outliers.append((int(n_contacts), float(dq)))
+            self.spreads.append(tuple(float(x) for x in sp))
         else:
             for k, v in enumerate(vals):
                 if v is not None:
                     self.worst[k] = max(self.worst[k], float(v))
 
     def report(self, tag):
-        allowed = max(1, int(np.ceil(0.004 * self.n_contact)))
+        allowed = max(1, int(np.ceil(0.003 * self.n_contact)))
         print(f"[float-parity] {tag}: {self.n} samples ({self.n_contact} with contacts), worst |dq| {self.worst[0]:.2e} rad"
               f"{'' if self.tol[1] is None else f', |dqd| {self.worst[1]:.2e} rad/s'}"
               f"{'' if self.tol[2] is None else f', torque {self.worst[2]:.2e} (relative)'}; "
-              f"outliers (n_contacts, |dq|): {self.outliers} (allowed {allowed})")
+              f"explained outliers (n_contacts, |dq|): {self.outliers}, oracle spreads {self.spreads} (allowed {allowed})")
         assert len(self.outliers) <= allowed, (self.outliers, allowed)
 
 
@@ -339,7 +368,7 @@ def test_one_step_parity_from_shared_states(name, steps, cfg_kw):
             act = rng.uniform(lo, hi, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, act)
         o = cpu.step(act)
         gq, _, _, gcol = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))
         pairs, counts, mask = gpu.contact_pairs()
@@ -350,7 +379,7 @@ def test_one_step_parity_from_shared_states(name, steps, cfg_kw):
         gcol = gcol.cpu().numpy()
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask, gcol):
-                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()), float(np.abs(gqd[e] - o["qd"][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()), float(np.abs(gqd[e] - o["qd"][e]).max()), env=e)
     ip.report(f"{name} {cfg_kw}")
     fp.report(f"{name} {cfg_kw}: {saw_contacts} contact rows, {saw_self} of them link-link")
     assert saw_contacts > 0
@@ -457,7 +486,7 @@ def test_random_trees_one_step_parity(case, tmp_path):
             act = rng.uniform(-1.0, 1.0, (n_envs, model.n_act)).astype(np.float32).astype(np.float64)
         cpu.state[:] = cpu.state.astype(np.float32)
         gpu.set_state(torch.tensor(cpu.state, dtype=torch.float32))
-        ip.pre(cpu)
+        ip.pre(cpu); fp.pre(cpu, act)
         o = cpu.step(act)
         gq = gpu.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"))[0].cpu().numpy()
         pairs, counts, mask = gpu.contact_pairs()
@@ -465,7 +494,7 @@ def test_random_trees_one_step_parity(case, tmp_path):
         contacts += int(o["n_contacts"].sum())
         for e in range(n_envs):
             if ip.check(e, o, counts, pairs, mask):
-                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()))
+                fp.add(o["n_contacts"][e], float(np.abs(gq[e] - o["q"][e]).max()), env=e)
     ip.report(f"random tree {case}")
     fp.report(f"random tree {case}")
     assert contacts > 0

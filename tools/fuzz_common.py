@@ -209,12 +209,17 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                     fail(e, t, int_why + f" (oracle under input noise: {sens:.3g} of the tolerance)", before, o, gq)
             if identical:
                 n_out = len(fp.outliers)
+                spread = None
+                if any(not v < tl for v, tl in zip(vals, fp.tol)):      # beyond a tolerance and steady under INPUT noise: must be explained
+                    spread = walk.noise_spread(before[e], act[e], joint_sel=sel, n_substeps=sub,      # by float32-sized noise on the rows
+                                               base_cmd_row=None if base_cmd is None else base_cmd[e], trials=256)
                 try:
-                    fp.add(nce, *vals)
+                    fp.add(nce, *vals, spread=spread)
                 except AssertionError as err:
                     fail(e, t, str(err), before, o, gq)
                 if len(fp.outliers) > n_out:
-                    print(f"  outlier: {tag.split(':')[0]} step {t} env {e}, {nce} contacts: %.3g rad, %.3g rad/s, torque %.3g (relative)" % vals)
+                    print(f"  explained outlier: {tag.split(':')[0]} step {t} env {e}, {nce} contacts: %.3g rad, %.3g rad/s, torque %.3g (relative)" % vals
+                          + "; oracle under row noise: %.3g rad, %.3g rad/s, torque %.3g" % fp.spreads[-1])
                     dump_sample(f"outlier_{tag.split(':')[0].replace(' ', '')}_{t}_{e}", e, before, o, gq)
         if t % 4 == 0:
             # getLinkState: the kernel's link poses from the kernel's OWN post-step state against the oracle's forward
