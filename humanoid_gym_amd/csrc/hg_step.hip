@@ -837,17 +837,19 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             R0.pw[0] = t.x; R0.pw[1] = t.y; R0.pw[2] = t.z;
         }
         RC.two_body = __ballot(RC.myanc2 != 0ull) != 0ull;   // wave-uniform
+        if constexpr (NOV > 0) R1.two_body = __ballot(R1.myanc2 != 0ull) != 0ull;
         lamL[lane] = R0.target_err;       // parked across the impulse-response pass (the impulses' own storage, unused until the sweeps end)
         wave_sync();
 
         HG_TICK(7);
-        // ---- 4a'. overflow rows (OVF): what the sweep needs of a row without a lane ------------------------------------
-        // Row o = friction row of the last contact slot(s).  Its entries against the rows that HAVE a lane are those lanes'
-        // own column o (A is symmetric; every lane accumulates all NC3 contact columns in 4a).  What is left are its entries
-        // against the overflow rows themselves, diagonal included: J_o' is non-zero only on the paths of the overflow
-        // contacts' bodies, so the response M^-1 J_o^T is evaluated along those paths only (lane k < NOV: row NCL + k) --
-        // the own-path walk towards the root, the base, then one descent per contact body -- instead of over the whole tree.
-        // Results as wave-uniform scalars: ov_b (desired change of J.v), ov_inv (1 / A_oo, 0 = row disabled), ov_a[k][k'].
+        // ---- 4a'. rows of row set 1 (DUAL: the contact rows; OVF: the overflow rows) -------------------------------------------
+        // Their entries against the MOTOR rows are not computed by a second response over the whole tree: A is symmetric, and
+        // the lane of motor row i accumulates all NC3 contact columns in 4a, so A[c][i] is lane i's own column c (DUAL: moved
+        // to lane c through LDS before the sweeps; OVF: used in place by the wave reduction).  What is left are their entries
+        // against the CONTACT rows, diagonal included: J_c' is non-zero only on the links of the contact paths (rowmask,
+        // closed under ancestors), so M^-1 J_c^T is evaluated on those links only -- the own-path walk towards the root, the
+        // base, then a descent that skips every link off the contact paths (`response` with PATHONLY).
+        // OVF results as wave-uniform scalars: ov_b (desired change of J.v), ov_inv (1 / A_oo, 0 = row disabled), ov_a[k][k'].
         float ov_b[NOV > 0 ? NOV : 1], ov_inv[NOV > 0 ? NOV : 1], ov_a[NOV > 0 ? NOV : 1][NOV > 0 ? NOV : 1];
 #pragma unroll
         for (int k = 0; k < (NOV > 0 ? NOV : 1); k++) {
@@ -855,114 +857,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
             for (int j = 0; j < (NOV > 0 ? NOV : 1); j++) ov_a[k][j] = 0.f;
         }
-        if constexpr (NOV > 0) {
-            if (ovf_on) {
-                const RowVars &R = R1;
-                const int col = R.col;
-                float XO[NOV], xdiag;
-                float Yo[DEPTH], Yo2[DEPTH];
-                Sv Z; Z.a = v3(0, 0, 0); Z.l = v3(0, 0, 0);
-#pragma unroll
-                for (int dd = DEPTH; dd >= 1; --dd) {
-                    float Y = 0.f;
-                    if (dd <= maxlev) {
-                        const int l = (int)((R.pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
-                        if (l >= 0) {
-                            const float *pc = cacheL + CACHE * l;
-                            Y = JcL[(6 + l) * NC3 + col] - sdot(ldsv(pc + C_SW), Z);
-                            Z = sfma(ldsv(pc + C_UW), Y * pc[C_DINV], Z);
-                            Z.a = Z.a + cross(ld3(pc + C_RW), Z.l);
-                        }
-                    }
-                    Yo[dd - 1] = Y;
-                }
-                const bool two = __ballot(R.myanc2 != 0ull) != 0ull;
-                Sv Z2; Z2.a = v3(0, 0, 0); Z2.l = v3(0, 0, 0);
-#pragma unroll
-                for (int dd = DEPTH; dd >= 1; --dd) {
-                    float Y = 0.f;
-                    if (two && dd <= maxlev) {
-                        const int l = (int)((R.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
-                        if (l >= 0) {
-                            const float *pc = cacheL + CACHE * l;
-                            const float f = ((R.myanc >> l) & 1ull) ? 0.f : JcL[(6 + l) * NC3 + col];      // shared links: net entry taken on the first path
-                            Y = f - sdot(ldsv(pc + C_SW), Z2);
-                            Z2 = sfma(ldsv(pc + C_UW), Y * pc[C_DINV], Z2);
-                            Z2.a = Z2.a + cross(ld3(pc + C_RW), Z2.l);
-                        }
-                    }
-                    Yo2[dd - 1] = Y;
-                }
-                Z = Z + Z2;
-                Z.a = Z.a - R.Jang;
-                Z.l = Z.l - R.Jlin;
-                const Sv ab = neg_mul6(baseL + 12, Z);
-                xdiag = dot(ab.a, R.Jang) + dot(ab.l, R.Jlin);
-                {
-                    const float ub[6] = {ab.a.x, ab.a.y, ab.a.z, ab.l.x, ab.l.y, ab.l.z};
-#pragma unroll
-                    for (int j = 0; j < NOV; j++) {
-                        float x = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) x = fmaf(ub[k], JcL[k * NC3 + NCL + j], x);
-                        XO[j] = x;
-                    }
-                }
-                // descents: the path of every body of every overflow contact (wave-uniform links, read from the lane that
-                // owns the contact's first friction row); a link met again on a later path is not accumulated twice
-                unsigned vis_lo = 0u, vis_hi = 0u;
-#pragma unroll
-                for (int oc = 0; oc < NOV / 2; ++oc) {
-                    if (OC0 + oc < nc) {
-#pragma unroll
-                        for (int which = 0; which < 2; ++which) {
-                            unsigned pwu[3];
-#pragma unroll
-                            for (int j = 0; j < 3; j++)
-                                pwu[j] = (unsigned)__builtin_amdgcn_readlane((int)(which ? R.pw2[j] : R.pw[j]), 2 * oc);
-                            Sv a = ab;
-#pragma unroll
-                            for (int dd = 1; dd <= DEPTH; ++dd) {
-                                if (dd <= maxlev) {
-                                    const int l = (int)((pwu[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;      // scalar
-                                    if (l >= 0) {
-                                        const float *pc = cacheL + CACHE * l;
-                                        a.l = a.l + cross(a.a, ld3(pc + C_RW));
-                                        const bool on1 = ((l < 32 ? (unsigned)R.myanc : (unsigned)(R.myanc >> 32)) >> (l & 31)) & 1u;
-                                        const bool on2 = ((l < 32 ? (unsigned)R.myanc2 : (unsigned)(R.myanc2 >> 32)) >> (l & 31)) & 1u;
-                                        const float Y = (on1 ? Yo[dd - 1] : 0.f) + (on2 ? Yo2[dd - 1] : 0.f);
-                                        const float qa = (Y - sdot(ldsv(pc + C_UW), a)) * pc[C_DINV];
-                                        a = sfma(ldsv(pc + C_SW), qa, a);
-                                        const bool seen = ((l < 32 ? vis_lo : vis_hi) >> (l & 31)) & 1u;
-                                        if (!seen) {
-                                            const float *jr = JcL + (6 + l) * NC3;
-#pragma unroll
-                                            for (int j = 0; j < NOV; j++) XO[j] = fmaf(qa, jr[NCL + j], XO[j]);
-                                            if (col >= 0) xdiag = fmaf(qa, jr[col], xdiag);
-                                        }
-                                        if (l < 32) vis_lo |= 1u << l; else vis_hi |= 1u << (l - 32);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                const float inv = (R.contact && xdiag > (float)HG_ROW_DEN_EPS) ? __builtin_amdgcn_rcpf(xdiag) : 0.f;      // else: row disabled
-#pragma unroll
-                for (int k = 0; k < NOV; k++) {
-                    ov_b[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R.target_err), k));
-                    ov_inv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), k));
-#pragma unroll
-                    for (int j = 0; j < NOV; j++)
-                        ov_a[k][j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(XO[j]), k));
-                }
-            }
-        }
         // ---- 4a. lane r: u_r = M^-1 J_r^T, and row r of A = J M^-1 J^T ----------------------------
         // Motor columns of the row: register vectors of up to 16 columns, so that column i (wave-uniform, known only
         // at run time in the descent below) is written with one indexed move (s_set_gpr_idx + v_mov)
         // instead of a 64-way switch; contact columns: plain registers, compile-time indices only.
-        HG_TICK(15);      // end of the overflow rows' path-only response (4a')
         typedef typename RegVec<clamp16(NMX)>::type VA0;
         typedef typename RegVec<clamp16(NMX - 16)>::type VA1;
         typedef typename RegVec<clamp16(NMX - 32)>::type VA2;
@@ -978,8 +876,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
         for (int k = 0; k < NC3; k++) BC[k] = 0.f;
         float diagB = 0.f;
-        auto response = [&](const RowVars &R, VA0 &XM0, VA1 &XM1, VA2 &XM2, VA3 &XM3, float (&XC)[NC3 > 0 ? NC3 : 1], float &xdiag)
+        auto response = [&](auto PO_, const RowVars &R, VA0 &XM0, VA1 &XM1, VA2 &XM2, VA3 &XM3, float (&XC)[NC3 > 0 ? NC3 : 1], float &xdiag)
                             __attribute__((always_inline)) {
+            constexpr bool PATHONLY = decltype(PO_)::value != 0;      // contact rows of row set 1: links on the contact paths only, no motor columns
             const int col = R.col, body = R.body;
             const bool unit_row = R.motor || R.slot;
             const unsigned pw[3] = {R.pw[0], R.pw[1], R.pw[2]};
@@ -1057,7 +956,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
 #pragma unroll
             for (int i = 0; i < NMX; ++i) {      // (a plain loop, fully unrolled: a closure per link sent the slots to scratch)
-                if (i < n) {
+                if (i < n && (!PATHONLY || ((rowmask >> i) & 1ull))) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
                 const int mode = (int)(inf & 0x3u);
                 const float *pc = cacheL + CACHE * i;
@@ -1094,10 +993,12 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                         else if (NSL > 1) slot1 = a;
                     }
                 }
-                if (i < 16) XM0[i % clamp16(NMX)] = qa;
-                else if (i < 32) XM1[(i - 16) % clamp16(NMX - 16)] = qa;
-                else if (i < 48) XM2[(i - 32) % clamp16(NMX - 32)] = qa;
-                else XM3[(i - 48) % clamp16(NMX - 48)] = qa;
+                if constexpr (!PATHONLY) {
+                    if (i < 16) XM0[i % clamp16(NMX)] = qa;
+                    else if (i < 32) XM1[(i - 16) % clamp16(NMX - 16)] = qa;
+                    else if (i < 48) XM2[(i - 32) % clamp16(NMX - 32)] = qa;
+                    else XM3[(i - 48) % clamp16(NMX - 48)] = qa;
+                }
                 if (unit_row && i == body) xdiag = R.unit_f * qa;
                 if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
@@ -1117,9 +1018,53 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
             }
         };
-        // DUAL: the contact rows (row set 1) first -- their set-up values die here -- then the motor rows
-        if constexpr (DUAL) { if (nc > 0) response(R1, BM0, BM1, BM2, BM3, BC, diagB); }
-        response(R0, AM0, AM1, AM2, AM3, AC, diag);
+        // row set 1 first -- its set-up values die here -- then the rows that have a lane
+        if constexpr (DUAL) { if (nc > 0) response(IC<1>{}, R1, BM0, BM1, BM2, BM3, BC, diagB); }
+        if constexpr (NOV > 0) {
+            if (ovf_on) {
+                response(IC<1>{}, R1, BM0, BM1, BM2, BM3, BC, diagB);
+                const float inv = (R1.contact && diagB > (float)HG_ROW_DEN_EPS) ? __builtin_amdgcn_rcpf(diagB) : 0.f;      // else: row disabled
+#pragma unroll
+                for (int k = 0; k < NOV; k++) {
+                    ov_b[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(R1.target_err), k));
+                    ov_inv[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), k));
+#pragma unroll
+                    for (int j = 0; j < NOV; j++)
+                        ov_a[k][j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(BC[NOV > 0 ? NCL + j : 0]), k));
+                }
+            }
+        }
+        HG_TICK(15);      // end of row set 1's path-only response (4a')
+        response(IC<0>{}, R0, AM0, AM1, AM2, AM3, AC, diag);
+        if constexpr (DUAL) {
+            // A[contact c][motor i] = A[motor i][contact c]: lane i's column c goes to lane c through LDS, in chunks of CH contact
+            // columns that fit the own-path Y storage (dead since the responses ended): T[(c - c0) * NMX + i]
+            static_assert(YSL, "two rows per lane keeps the own-path Y values in LDS: the transposition buffer");
+            constexpr int CH = (DEPTH * WAVE) / NMX < NC3 ? (DEPTH * WAVE) / NMX : NC3;
+            static_assert(CH >= 1, "transposition chunk");
+            if (nc > 0) {
+#pragma unroll
+                for (int c0 = 0; c0 < NC3; c0 += CH) {
+                    wave_sync();
+                    if (lane < NMX) {
+#pragma unroll
+                        for (int c = 0; c < CH; c++) if (c0 + c < NC3) ysL[c * NMX + lane] = AC[c0 + c < NC3 ? c0 + c : 0];
+                    }
+                    wave_sync();
+                    if (lane >= c0 && lane < c0 + CH && lane < NC3) {
+                        const float *t = ysL + (lane - c0) * NMX;
+#pragma unroll
+                        for (int i = 0; i < NMX; i++) {
+                            const float v = t[i];
+                            if (i < 16) BM0[i % clamp16(NMX)] = v;
+                            else if (i < 32) BM1[(i - 16) % clamp16(NMX - 16)] = v;
+                            else if (i < 48) BM2[(i - 32) % clamp16(NMX - 32)] = v;
+                            else BM3[(i - 48) % clamp16(NMX - 48)] = v;
+                        }
+                    }
+                }
+            }
+        }
         const bool row_motor = R0.motor, row_slot = R0.slot;
         const bool row_contact = DUAL ? false : R0.contact;      // set-0 view (one row per lane): the solver below
         const int col = DUAL ? -1 : R0.col;

@@ -322,6 +322,9 @@ def test_dancer_self_collision_rows():
     # 12 steps above: the parity statement is the one-step comparison from shared states below.
     print(f"[free run] dancer self-collision: {same}/{100 * n_envs} (env, step) samples with identical pair lists, "
           f"worst |dq| per env {np.round(worst, 4).tolist()}")
+    # ... but a bound on the free run is kept: measured 392/400 identical pair lists and 0.031 rad in the
+    # worst env over the 100 steps; a kernel that is wrong, not merely float32, separates at once and everywhere
+    assert same >= 0.9 * 100 * n_envs and worst.max() < 0.15 and np.median(worst) < 5e-3
     assert saw_self
     assert set(map(tuple, o["pairs"][0, :o["n_contacts"][0]].tolist())) >= {(11, 17)}
     st = gpu.get_state().cpu().numpy()
