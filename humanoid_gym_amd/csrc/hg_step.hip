@@ -91,6 +91,11 @@ HG_FI void wave_sync() {
 // rows"): operands z, l (lane impulses), c, d (temporaries), s (SGPR), m (SGPR pair), lo, hi, a<K> (column), lane i0 SGN K.
 #define HG_ROW_ASM(K, SGN) "v_med3_f32 %[c], %[z], %[lo], %[hi]\n\tv_sub_f32 %[d], %[c], %[l]\n\ts_lshl_b64 %[m], 1, %[i0]" SGN #K "\n\t" \
     "v_readlane_b32 %[s], %[d], %[i0]" SGN #K "\n\tv_cndmask_b32_e64 %[l], %[l], %[c], %[m]\n\ts_nop 0\n\tv_fmac_f32 %[z], %[s], %[a" #K "]\n\t"
+// the same for two rows per lane (DUAL): the row lives in z / l (a motor row) and its change goes to both candidates
+#define HG_DROW_ASM(K, SGN) "v_med3_f32 %[c], %[z], %[lo], %[hi]\n\tv_sub_f32 %[d], %[c], %[l]\n\ts_lshl_b64 %[m], 1, %[i0]" SGN #K "\n\t" \
+    "v_readlane_b32 %[s], %[d], %[i0]" SGN #K "\n\tv_cndmask_b32_e64 %[l], %[l], %[c], %[m]\n\ts_nop 0\n\tv_fmac_f32 %[z], %[s], %[a" #K "]\n\t" \
+    "v_fmac_f32 %[z1], %[s], %[b" #K "]\n\t"
+#define HG_DROWS4_ASM(SGN) HG_DROW_ASM(0, SGN) HG_DROW_ASM(1, SGN) HG_DROW_ASM(2, SGN) HG_DROW_ASM(3, SGN)
 #define HG_ROWS2_ASM(SGN) HG_ROW_ASM(0, SGN) HG_ROW_ASM(1, SGN)
 #define HG_ROWS6_ASM(SGN) HG_ROW_ASM(0, SGN) HG_ROW_ASM(1, SGN) HG_ROW_ASM(2, SGN) HG_ROW_ASM(3, SGN) HG_ROW_ASM(4, SGN) HG_ROW_ASM(5, SGN)
 
@@ -1545,21 +1550,40 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             else if (i < 48) return BM2[i >= 32 && i < 48 && i < NMX ? i - 32 : 0];
             else return BM3[i >= 48 && i < NMX ? i - 48 : 0];
         };
+        // Row updates as blocks of assembly, eight issue slots per row (see the one-row-per-lane solver with overflow rows
+        // above for the wait states and the one-lane select): the row's change goes to both candidates.
         auto motor_update = [&](const int i) {
-            const float cand = __builtin_amdgcn_fmed3f(z, lo, hi);
-            const float s_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lamv0), i));
-            z = fmaf(colA(i), s_d, z);
-            z1 = fmaf(colB(i), s_d, z1);      // unconditional: without contacts the B columns are all zero (a test per row costs a v_cndmask)
-            asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
-                         : "+v"(lamv0) : "v"(cand), "i"(i < 32 ? (int)(1u << (i & 31)) : 0), "i"(i >= 32 ? (int)(1u << (i & 31)) : 0));
+            float cand, d; int sd; unsigned long long m1;
+            asm(HG_DROW_ASM(0, "+") : [z] "+v"(z), [z1] "+v"(z1), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                : [a0] "v"(colA(i)), [b0] "v"(colB(i)), [lo] "v"(lo), [hi] "v"(hi), [i0] "n"(i) : "scc");
+        };
+        auto motor_rows4 = [&](const int i0, const bool fwd) {      // rows i0, i0 +- 1, i0 +- 2, i0 +- 3
+            float cand, d; int sd; unsigned long long m1;
+            const int sg = fwd ? 1 : -1;
+            if (fwd)
+                asm(HG_DROWS4_ASM("+") : [z] "+v"(z), [z1] "+v"(z1), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(colA(i0)), [a1] "v"(colA(i0 + sg)), [a2] "v"(colA(i0 + 2 * sg)), [a3] "v"(colA(i0 + 3 * sg)),
+                      [b0] "v"(colB(i0)), [b1] "v"(colB(i0 + sg)), [b2] "v"(colB(i0 + 2 * sg)), [b3] "v"(colB(i0 + 3 * sg)),
+                      [lo] "v"(lo), [hi] "v"(hi), [i0] "n"(i0) : "scc");
+            else
+                asm(HG_DROWS4_ASM("-") : [z] "+v"(z), [z1] "+v"(z1), [l] "+v"(lamv0), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                    : [a0] "v"(colA(i0)), [a1] "v"(colA(i0 + sg)), [a2] "v"(colA(i0 + 2 * sg)), [a3] "v"(colA(i0 + 3 * sg)),
+                      [b0] "v"(colB(i0)), [b1] "v"(colB(i0 + sg)), [b2] "v"(colB(i0 + 2 * sg)), [b3] "v"(colB(i0 + 3 * sg)),
+                      [lo] "v"(lo), [hi] "v"(hi), [i0] "n"(i0) : "scc");
+        };
+        auto motor_run = [&](const bool fwd) __attribute__((always_inline)) {      // all NMX motor rows, ascending or descending
+            int k = 0;
+#pragma unroll
+            for (; k + 4 <= NMX; k += 4) motor_rows4(fwd ? k : NMX - 1 - k, fwd);
+#pragma unroll
+            for (; k < NMX; k += 1) motor_update(fwd ? k : NMX - 1 - k);
         };
         auto contact_update = [&](const int c, const float rlo, const float rhi) {       // contact row c: lane c of row set 1
-            const float cand = __builtin_amdgcn_fmed3f(z1, rlo, rhi);
-            const float s_d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand - lamv1), c));
-            z = fmaf(AC[c], s_d, z);
-            z1 = fmaf(BC[c], s_d, z1);
-            asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, %3\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, -1"
-                         : "+v"(lamv1) : "v"(cand), "i"(c < 32 ? (int)(1u << (c & 31)) : 0), "i"(c >= 32 ? (int)(1u << (c & 31)) : 0));
+            float cand, d; int sd; unsigned long long m1;
+            asm("v_med3_f32 %[c], %[z1], %[lo], %[hi]\n\tv_sub_f32 %[d], %[c], %[l]\n\ts_lshl_b64 %[m], 1, %[i0]\n\tv_readlane_b32 %[s], %[d], %[i0]\n\t"
+                "v_cndmask_b32_e64 %[l], %[l], %[c], %[m]\n\ts_nop 0\n\tv_fmac_f32 %[z], %[s], %[a0]\n\tv_fmac_f32 %[z1], %[s], %[b0]"
+                : [z] "+v"(z), [z1] "+v"(z1), [l] "+v"(lamv1), [c] "=&v"(cand), [d] "=&v"(d), [s] "=&s"(sd), [m] "=&s"(m1)
+                : [a0] "v"(AC[c]), [b0] "v"(BC[c]), [lo] "v"(rlo), [hi] "v"(rhi), [i0] "n"(c) : "scc");
         };
         auto contact_rows = [&]() {
             if (nc > 0) {
@@ -1623,11 +1647,9 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     #pragma unroll 1
                     for (unsigned long long mk = limmask; mk != 0ull; mk &= mk - 1ull) limit_update_idx(__builtin_ctzll(mk));
                 }
-#pragma unroll
-                for (int i = 0; i < NMX; ++i) motor_update(i);
+                motor_run(true);
             } else {
-#pragma unroll
-                for (int i = NMX - 1; i >= 0; --i) motor_update(i);
+                motor_run(false);
                 if constexpr (LIM_SCAN) {
                     if (limmask != 0ull) {
 #pragma unroll
