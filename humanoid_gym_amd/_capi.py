@@ -25,7 +25,7 @@ SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_res
 
 
 # the ABI version that the ctypes mirrors in model.py (HgModel, HgConfig) and the prototypes below are written for
-HG_ABI_VERSION = 6
+HG_ABI_VERSION = 7
 
 
 class HgError(RuntimeError):

@@ -1,7 +1,7 @@
 // hg_device.h -- device-side data layout of libhg_sim (gfx950 only).
 //
 // One wavefront (64 lanes) simulates one env.  The robot description is a
-// single read-only DevModel in HBM (27 KB, L2 resident); per-env state
+// single read-only DevModel in HBM (~75 KB, L2 resident); per-env state
 // is an env-major float record (include/hg_model.h, HG_STATE_SIZE; padded in the library's own
 // buffer to a whole number of 64-byte lines) so that the 64 lanes of the env's wave read and write
 // it as one contiguous, line-aligned burst.
@@ -28,6 +28,9 @@ __host__ __device__ constexpr int cache_stride(int nmx) { return nmx > 48 ? 24 :
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
 constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
 constexpr int CON   = 12;   // floats per contact record
+constexpr int SCEN  = 8;    // floats per link-link primitive in LDS: world centre, radius, world half axis, pad
+#define HG_DEV_SPHERES 2048 // device slots for HG_MAX_SPHERES primitives + padding
+#define HG_DEV_SELF    256  // primitives that appear in link-link pairs (8-bit indices in pair_meta)
 // the cache record of a link (world-aligned axes, origin at the link's COM; hg_step.hip, phase 1)
 constexpr int C_RW = 0, C_DINV = 3, C_UW = 4, C_SW = 10, C_XW = 16, C_U = 19, C_MAXVEL = 20, C_MAXIMP = 21;
 
@@ -55,19 +58,16 @@ struct DevModel {
     int32_t  lev_start[DMAX + 4];       // links of level l: lev_order[lev_start[l] .. lev_start[l + 1])
     int8_t   lev_order[HG_MAX_LINKS];   // link indices sorted by level
     uint32_t pathw[HG_MAX_LINKS][4];    // byte d-1 of the 16: path[b][d-1] + 1 (0 = none)
-    uint32_t sphere_meta[HG_MAX_SPHERES]; // (link + 1) | flags << 8 | grp_begin << 16 | grp_end << 24
+    // collision primitives in DEVICE order: the model's order, with padding slots (meta 0) inserted so that the primitives
+    // of one body never straddle a trip of 64 slots (the wave ranks a body's ground points inside one 64-float LDS window)
+    uint32_t sphere_meta[HG_DEV_SPHERES]; // (link + 1) | flags << 8 (bit 8 ground, 9 link-link, 15 appears in a pair) | body's first slot in its trip << 16 | one past its last << 24
     uint32_t pair_meta[HG_MAX_PAIRS];     // self index a | self index b << 8 | (link a + 1) << 16 | (link b + 1) << 24
-    uint8_t  self_idx[HG_MAX_SPHERES];    // compact index of a sphere among those that take part in self-collision pairs
+    uint8_t  self_idx[HG_DEV_SPHERES];    // compact index of a primitive among those that take part in link-link pairs
     unsigned long long anc_mask[HG_MAX_LINKS];  // bit j: j is b or an ancestor of b
     float   link[HG_MAX_LINKS][LINKC];
     float   base[32];
-    int16_t sphere_link[HG_MAX_SPHERES];
-    int16_t grp_begin[HG_MAX_SPHERES];  // [begin,end): spheres on the same body (contiguous)
-    int16_t grp_end[HG_MAX_SPHERES];
-    uint8_t sphere_flags[HG_MAX_SPHERES];
-    float   sphere[HG_MAX_SPHERES][4];  // x y z radius, internal frame of the body
-    int16_t pair_a[HG_MAX_PAIRS];
-    int16_t pair_b[HG_MAX_PAIRS];
+    float   sphere[HG_DEV_SPHERES][4];  // x y z radius, internal frame of the body
+    float   self_half[HG_DEV_SELF][4];  // half axis of the sphere-swept segments (by self index), internal frame; 0 = sphere
     float   frame_pos[HG_MAX_LINKS + 1][4];
     float   frame_quat[HG_MAX_LINKS + 1][4];
 };
@@ -102,7 +102,7 @@ struct LdsPlan {
     int cache, base, vel, F, lam, misc, con, Yd2, sdist, scen, tab, ys, AB, acc, total;
 };
 // With self-collision two more arrays exist, never live together, so they share one region: the world centres
-// (+ radius) of the n_self spheres that appear in pairs (contact detection), and the second-path Y values of
+// (+ radius, half axis) of the n_self primitives that appear in pairs (contact detection), and the second-path Y values of
 // two-body rows, kept for the contact-row lanes only (maxlev x nc3, phase 4a).
 __host__ __device__ inline int rup4(int x) { return (x + 3) & ~3; }
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
@@ -130,11 +130,12 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int ns, int nc3, int maxlev, 
     p.vel = o;   p.F = o;    o += imax(ndof, rup4(n));
     p.lam = o;   p.misc = o; o += nrows > WAVE ? WAVE + rup4(nc3) : WAVE;      // impulses of all rows (two rows per lane beyond 64)
     p.con = o;   o += CON * (nc3 / 3);
-    p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, 4 * n_self)) : 0;
+    p.Yd2 = o;   p.scen = o; o += n_self > 0 ? rup4(imax(maxlev * nc3, SCEN * n_self)) : 0;
     p.tab = o;   o += rup4(n);              // byte tables (4 n bytes): next_sibling, base_children, first_child, lev_order
-    // the sphere - plane distances are dead once the contacts are found: the Y values of the response pass are laid over them
+    // the point - plane distances of one trip of 64 primitives (contact detection); dead once the contacts are found: the
+    // Y values of the response pass are laid over them
     p.ys = o;
-    p.sdist = o; o += rup4(ns);
+    p.sdist = o; o += ns > 0 ? WAVE : 0;
     o = imax(o, p.ys + ys);
     p.AB = o;    o += rup4(imax(imax(PUB * (n + 1), UP * n), imax((6 + n) * nc3, 16 * n + 8)));
     p.acc = o;   o += 8 * (n + 1);

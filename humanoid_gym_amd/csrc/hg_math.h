@@ -199,4 +199,27 @@ HG_FI Sv neg_mul6(const float *Inv, Sv z) {
     return r;
 }
 
+// Closest points of two sphere-swept segments (centre c, half axis h; h = 0: a sphere), the float32 statement of
+// oracle/hg_oracle.c seg_seg_closest: exact solution (cross-product form: no cancellation in the denominator) blended
+// towards the centre of the overlap interval as the segments become parallel, so that the contact point is continuous in
+// the pose.  c1 on a, c2 on b.
+#define HG_SEG_EPS   1e-12f
+#define HG_SEG_BLEND 0.03f
+HG_FI float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+HG_FI void seg_seg_closest(V3 ca, V3 ha, V3 cb, V3 hb, V3 &c1, V3 &c2) {
+    const V3 p1 = ca - ha, d1 = ha * 2.f, p2 = cb - hb, d2 = hb * 2.f, r = p1 - p2;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    const float ia = a > HG_SEG_EPS ? 1.f / a : 0.f, ie = e > HG_SEG_EPS ? 1.f / e : 0.f;
+    const V3 nx = cross(d1, d2);
+    const float ae = a * e, denom = dot(nx, nx);
+    const float w = denom < HG_SEG_BLEND * ae ? denom / (HG_SEG_BLEND * ae) : 1.f;
+    const float s_exact = denom > 0.f ? clamp01(-dot(cross(r, d2), nx) / denom) : 0.f;
+    const float sb0 = -c * ia, sb1 = (b - c) * ia;
+    const float s_mid = 0.5f * (clamp01(fminf(sb0, sb1)) + clamp01(fmaxf(sb0, sb1)));
+    float s = s_mid + w * (s_exact - s_mid);
+    const float t = clamp01((b * s + f) * ie);
+    s = clamp01((b * t - c) * ia);
+    c1 = p1 + d1 * s; c2 = p2 + d2 * t;
+}
+
 }  // namespace hg

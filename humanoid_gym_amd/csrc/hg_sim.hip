@@ -294,7 +294,7 @@ static int check_numbers(const hg_model *m, const hg_config *c, std::string *why
     for (int b = 0; b <= m->n_links; b++)
         if (!fin(m->frame_pos[b], 3) || !fin(m->frame_quat[b], 4)) return bad("URDF frame offsets must be finite", b);
     for (int s = 0; s < m->n_spheres; s++)
-        if (!fin(m->sphere_pos[s], 3) || !(m->sphere_radius[s] >= 0) || !std::isfinite(m->sphere_radius[s])) return bad("collision sphere centre / radius must be finite, radius >= 0", s);
+        if (!fin(m->sphere_pos[s], 3) || !fin(m->sphere_half[s], 3) || !(m->sphere_radius[s] >= 0) || !std::isfinite(m->sphere_radius[s])) return bad("collision primitive centre / half axis / radius must be finite, radius >= 0", s);
     if (!fin(c->gravity, 3) || !(c->kp >= 0) || !(c->kd >= 0) || !(c->contact_erp >= 0) || !(c->friction >= 0) || !(c->lin_damping >= 0) ||
         !(c->ang_damping >= 0) || !(c->limit_max_impulse >= 0) || !std::isfinite(c->contact_margin) || std::isnan(c->max_coord_velocity) ||
         !std::isfinite(c->kp) || !std::isfinite(c->kd) || !std::isfinite(c->contact_erp) || !std::isfinite(c->friction) ||
@@ -407,28 +407,37 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         for (int k = 0; k < 3; k++) D->frame_pos[b][k] = (float)m->frame_pos[b][k];
         for (int k = 0; k < 4; k++) D->frame_quat[b][k] = (float)m->frame_quat[b][k];
     }
-    for (int s = 0; s < m->n_spheres; s++) {
-        if (m->sphere_link[s] < -1 || m->sphere_link[s] >= n) { *why = "sphere_link out of range"; return HG_EINVAL; }
-        D->sphere_link[s] = (int16_t)m->sphere_link[s];
-        D->sphere_flags[s] = (uint8_t)m->sphere_flags[s];
-        for (int k = 0; k < 3; k++) D->sphere[s][k] = (float)m->sphere_pos[s][k];
-        D->sphere[s][3] = (float)m->sphere_radius[s];
-    }
-    // same-body groups; the "4 deepest per body" rule ranks inside a group, so the
-    // spheres of a body must be contiguous: verify rather than assume
+    // Collision primitives -> device slots.  The "4 deepest points per body" rule ranks inside a body's group, which the
+    // kernel does in a 64-float LDS window per trip of 64 slots: the primitives of a body must be contiguous (verified, not
+    // assumed), at most 64, and padding slots are inserted so that no group straddles a trip.  The order of the model is
+    // kept -- it is the order in which contacts take their slots (oracle/hg_oracle.c detect_contacts).
+    static_assert(HG_DEV_SELF <= 256 && WAVE == 64, "pair_meta packs 8-bit self indices; sphere_meta 8-bit window offsets");
+    int dev_of[HG_MAX_SPHERES], nd = 0;
     for (int s = 0; s < m->n_spheres;) {
+        const int link = m->sphere_link[s];
+        if (link < -1 || link >= n) { *why = "sphere_link out of range"; return HG_EINVAL; }
         int e = s;
-        while (e < m->n_spheres && m->sphere_link[e] == m->sphere_link[s]) e++;
+        while (e < m->n_spheres && m->sphere_link[e] == link) e++;
         for (int o = e; o < m->n_spheres; o++)
-            if (m->sphere_link[o] == m->sphere_link[s]) { *why = "collision spheres of one body must be contiguous"; return HG_EINVAL; }
-        for (int k = s; k < e; k++) {
-            D->grp_begin[k] = (int16_t)s; D->grp_end[k] = (int16_t)e;
-            D->sphere_meta[k] = (uint32_t)(uint8_t)(m->sphere_link[k] + 1) | ((uint32_t)(m->sphere_flags[k] & 0x3) << 8) |
-                                ((uint32_t)s << 16) | ((uint32_t)e << 24);
+            if (m->sphere_link[o] == link) { *why = "collision primitives of one body must be contiguous"; return HG_EINVAL; }
+        const int cnt = e - s;
+        if (cnt > WAVE) { *why = "more than 64 collision primitives on one body"; return HG_EUNSUPPORTED; }
+        if (nd % WAVE + cnt > WAVE) nd = (nd + WAVE - 1) / WAVE * WAVE;
+        if (nd + cnt > HG_DEV_SPHERES) { *why = "collision primitives (with trip padding) exceed the device table"; return HG_EUNSUPPORTED; }
+        const int g0 = nd % WAVE;
+        for (int k = s; k < e; k++, nd++) {
+            const double *h = m->sphere_half[k];
+            if ((m->sphere_flags[k] & 1) && (h[0] != 0 || h[1] != 0 || h[2] != 0)) { *why = "a ground primitive must be a point or a sphere (sphere_half = 0)"; return HG_EINVAL; }
+            dev_of[k] = nd;
+            D->sphere_meta[nd] = (uint32_t)(uint8_t)(link + 1) | ((uint32_t)(m->sphere_flags[k] & 0x3) << 8) |
+                                 ((uint32_t)g0 << 16) | ((uint32_t)(g0 + cnt) << 24);
+            for (int j = 0; j < 3; j++) D->sphere[nd][j] = (float)m->sphere_pos[k][j];
+            D->sphere[nd][3] = (float)m->sphere_radius[k];
         }
         s = e;
     }
-    // spheres that appear in some pair get a compact index: only their world centres are kept in LDS
+    D->n_spheres = nd;
+    // primitives that appear in some pair get a compact index: only their world centres / half axes are kept in LDS
     int self_of[HG_MAX_SPHERES], n_self = 0;
     for (int s = 0; s < m->n_spheres; s++) self_of[s] = -1;
     for (int k = 0; k < m->n_pairs; k++) {
@@ -439,14 +448,17 @@ static int build_dev_model(const hg_model *m, const hg_config *c, DevModel *D, s
         self_of[m->pair_a[k]] = self_of[m->pair_b[k]] = 0;
     }
     for (int s = 0; s < m->n_spheres; s++)
-        if (self_of[s] == 0) { self_of[s] = n_self; D->self_idx[s] = (uint8_t)n_self; n_self++; D->sphere_flags[s] |= 0x80; D->sphere_meta[s] |= 0x8000u; }
+        if (self_of[s] == 0) {
+            if (n_self >= HG_DEV_SELF) { *why = "more than 256 primitives in link-link pairs"; return HG_EUNSUPPORTED; }
+            self_of[s] = n_self; D->self_idx[dev_of[s]] = (uint8_t)n_self; D->sphere_meta[dev_of[s]] |= 0x8000u;
+            for (int j = 0; j < 3; j++) D->self_half[n_self][j] = (float)m->sphere_half[s][j];
+            n_self++;
+        }
     D->n_self = c->enable_self ? n_self : 0;
-    for (int k = 0; k < m->n_pairs; k++) {
-        D->pair_a[k] = (int16_t)m->pair_a[k]; D->pair_b[k] = (int16_t)m->pair_b[k];
+    for (int k = 0; k < m->n_pairs; k++)
         D->pair_meta[k] = (uint32_t)self_of[m->pair_a[k]] | ((uint32_t)self_of[m->pair_b[k]] << 8) |
                           ((uint32_t)(uint8_t)(m->sphere_link[m->pair_a[k]] + 1) << 16) |
                           ((uint32_t)(uint8_t)(m->sphere_link[m->pair_b[k]] + 1) << 24);
-    }
     return HG_OK;
 }
 
@@ -460,7 +472,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 6; }
+int hg_abi_version(void) { return 7; }
 
 #ifdef HG_PHASE_TIMING
 // diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch (of the variant launched last)
@@ -533,7 +545,7 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     s->state_size = HG_STATE_SIZE(n); s->variant = variant; s->cfg = *config;
     s->state_stride = (s->state_size + 15) & ~15;      // records start on 64-byte lines: no partial-line traffic
     memcpy(s->act_joint, model->act_joint, sizeof(s->act_joint));
-    s->lds_bytes = (int)sizeof(float) * lds_plan(n, model->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self,
+    s->lds_bytes = (int)sizeof(float) * lds_plan(n, hm->n_spheres, 3 * kVariants[variant].maxc, hm->maxlev, hm->n_self,
                                                        kVariants[variant].nmx + 3 * kVariants[variant].maxc,
                                                        ys_floats(kVariants[variant].nmx, kVariants[variant].maxc, kVariants[variant].depth),
                                                        cache_stride(kVariants[variant].nmx)).total;

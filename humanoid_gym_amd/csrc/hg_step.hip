@@ -335,72 +335,77 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         nc = 0;
         link_mask = 0;
         if (P.flags & (F_GROUND | F_SELF)) {
-            #pragma unroll 1
-            for (int s = lane; s < ns; s += WAVE) {
-                const unsigned meta = M->sphere_meta[s];
-                const int b = (int)(meta & 0xffu) - 1;
-                const float *pp = pubL + PUB * (b < 0 ? n : b);
-                const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
-                const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
-                sdistL[s] = ((meta & 0x100u) && (P.flags & F_GROUND)) ? c.z - sp.w : 1e30f;
-                if ((P.flags & F_SELF) && (meta & 0x8000u)) {      // this sphere appears in a pair: keep its centre
-                    float *pc4 = scenL + 4 * (int)M->self_idx[s];
-                    st3(pc4, c); pc4[3] = sp.w;
-                }
-            }
-            wave_sync();
+            // Trips of 64 device slots (hg_sim.hip build_dev_model: a body's primitives never straddle a trip).  Per trip:
+            // world centre of this lane's primitive, its height over the plane into a 64-float window, rank among the
+            // points of the same body inside the window (the 4 deepest within the margin become contacts, in slot
+            // order), and the centre / radius / world half axis of the link-link primitives into `scen`.
             int count = 0;
-            if (P.flags & F_GROUND) {
-                #pragma unroll 1
-                for (int s0 = 0; s0 < ns; s0 += WAVE) {
-                    const int s = s0 + lane;
+            #pragma unroll 1
+            for (int s0 = 0; s0 < ns; s0 += WAVE) {
+                const int s = s0 + lane;
+                const unsigned meta = s < ns ? M->sphere_meta[s] : 0u;      // 0: padding slot
+                float d = 1e30f;
+                V3 c = v3(0, 0, 0);
+                const int b = (int)(meta & 0xffu) - 1;
+                if (meta != 0u) {
+                    const float *pp = pubL + PUB * (b < 0 ? n : b);
+                    const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
+                    const M3 Rb = ldm(pp);
+                    c = ld3(pp + 9) + mulv(Rb, v3(sp.x, sp.y, sp.z));
+                    if ((meta & 0x100u) && (P.flags & F_GROUND)) d = c.z - sp.w;
+                    if ((P.flags & F_SELF) && (meta & 0x8000u)) {      // appears in a pair: keep centre, radius, half axis
+                        const int si = (int)M->self_idx[s];
+                        const float4 hh = *reinterpret_cast<const float4 *>(M->self_half[si]);
+                        float *pc8 = scenL + SCEN * si;
+                        st3(pc8, c); pc8[3] = sp.w;
+                        st3(pc8 + 4, mulv(Rb, v3(hh.x, hh.y, hh.z)));
+                    }
+                }
+                if (P.flags & F_GROUND) {
+                    sdistL[lane] = d;
+                    wave_sync();
                     bool act = false;
-                    float d = 1e30f;
-                    unsigned meta = 0;
-                    if (s < ns) {
-                        d = sdistL[s];
-                        if (d < P.margin) {
-                            meta = M->sphere_meta[s];
-                            int rank = 0;
-                            const int ge = (int)(meta >> 24);
-                            #pragma unroll 1
-                            for (int o = (int)((meta >> 16) & 0xffu); o < ge; ++o) {
-                                const float od = sdistL[o];
-                                rank += (o != s && od < P.margin && (od < d || (od == d && o < s))) ? 1 : 0;
-                            }
-                            act = rank < 4;
+                    if (d < P.margin) {
+                        int rank = 0;
+                        const int ge = (int)(meta >> 24);
+                        #pragma unroll 1
+                        for (int o = (int)((meta >> 16) & 0xffu); o < ge; ++o) {
+                            const float od = sdistL[o];
+                            rank += (o != lane && od < P.margin && (od < d || (od == d && o < lane))) ? 1 : 0;
                         }
+                        act = rank < 4;
                     }
                     const unsigned long long bal = __ballot(act);
                     const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
                     if (act && slot < P.maxc) {
-                        const int b = (int)(meta & 0xffu) - 1;
-                        const float *pp = pubL + PUB * (b < 0 ? n : b);
-                        const float4 sp = *reinterpret_cast<const float4 *>(M->sphere[s]);
-                        const V3 c = ld3(pp + 9) + mulv(ldm(pp), v3(sp.x, sp.y, sp.z));
                         float *co = conL + CON * slot;
                         co[0] = __int_as_float(b); co[1] = __int_as_float(-2);
                         co[2] = c.x; co[3] = c.y; co[4] = d;
                         co[5] = 0.f; co[6] = 0.f; co[7] = 1.f; co[8] = d;
                     }
                     count += __popcll(bal);
+                    wave_sync();      // the next trip rewrites the window
                 }
             }
+            wave_sync();
             if (P.flags & F_SELF) {
-                // sphere pairs of bodies that are not ancestors of one another, in pair order
+                // pairs of sphere-swept segments on bodies that are not ancestors of one another, in pair order
                 const int np = P.n_pairs;
                 #pragma unroll 1
                 for (int p0 = 0; p0 < np && count < P.maxc; p0 += WAVE) {
                     const int p = p0 + lane;
                     bool act = false;
                     unsigned pr = 0;
-                    V3 d = v3(0, 0, 0), ca = d, cb = d;
+                    V3 d = v3(0, 0, 0), c1 = d, c2 = d;
                     float len = 1.f, ds = 0.f, ra = 0.f, rb = 0.f;
                     if (p < np) {
                         pr = M->pair_meta[p];
-                        const float *pa = scenL + 4 * (pr & 0xffu), *pb = scenL + 4 * ((pr >> 8) & 0xffu);
-                        ca = ld3(pa); cb = ld3(pb); ra = pa[3]; rb = pb[3];
-                        d = ca - cb;
+                        const float *pa = scenL + SCEN * (pr & 0xffu), *pb = scenL + SCEN * ((pr >> 8) & 0xffu);
+                        const float4 a0 = *reinterpret_cast<const float4 *>(pa), a1 = *reinterpret_cast<const float4 *>(pa + 4);
+                        const float4 b0 = *reinterpret_cast<const float4 *>(pb), b1 = *reinterpret_cast<const float4 *>(pb + 4);
+                        ra = a0.w; rb = b0.w;
+                        seg_seg_closest(v3(a0.x, a0.y, a0.z), v3(a1.x, a1.y, a1.z), v3(b0.x, b0.y, b0.z), v3(b1.x, b1.y, b1.z), c1, c2);
+                        d = c1 - c2;
                         len = sqrtf(dot(d, d));
                         ds = len - ra - rb;
                         act = ds < P.margin && len >= 1e-9f;
@@ -409,7 +414,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     const int slot = count + __popcll(bal & ((1ull << lane) - 1ull));
                     if (act && slot < P.maxc) {
                         const V3 nrm = d * __frcp_rn(len);
-                        const V3 pt = ((ca - nrm * ra) + (cb + nrm * rb)) * 0.5f;
+                        const V3 pt = ((c1 - nrm * ra) + (c2 + nrm * rb)) * 0.5f;
                         float *co = conL + CON * slot;
                         co[0] = __int_as_float((int)((pr >> 16) & 0xffu) - 1);
                         co[1] = __int_as_float((int)((pr >> 24) & 0xffu) - 1);

@@ -13,12 +13,12 @@ from __future__ import annotations
 import ctypes as C
 import json
 from dataclasses import dataclass, field
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 
 HG_MAX_LINKS = 62
-HG_MAX_SPHERES = 192
+HG_MAX_SPHERES = 1024
 HG_MAX_PAIRS = 1024
 HG_MAX_CONTACTS = 12
 HG_MAX_ROWS = 128
@@ -61,6 +61,7 @@ class HgModel(C.Structure):
         ("sphere_flags", C.c_int32 * HG_MAX_SPHERES),
         ("sphere_pos", (C.c_double * 3) * HG_MAX_SPHERES),
         ("sphere_radius", C.c_double * HG_MAX_SPHERES),
+        ("sphere_half", (C.c_double * 3) * HG_MAX_SPHERES),
         ("pair_a", C.c_int32 * HG_MAX_PAIRS),
         ("pair_b", C.c_int32 * HG_MAX_PAIRS),
     ]
@@ -181,6 +182,11 @@ class FlatModel:
     pair_b: np.ndarray
     act_joint: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     meta: Dict = field(default_factory=dict)
+    sphere_half: Optional[np.ndarray] = None      # [n_spheres, 3] half axis of a sphere-swept segment, 0 = sphere (None: all spheres)
+
+    def __post_init__(self):
+        if self.sphere_half is None or len(self.sphere_half) != len(self.sphere_link):
+            self.sphere_half = np.zeros((len(self.sphere_link), 3))
 
     # ------------------------------------------------------------------
     @property
@@ -276,6 +282,7 @@ class FlatModel:
             m.sphere_flags[s] = int(self.sphere_flags[s])
             m.sphere_pos[s][:] = self.sphere_pos[s].tolist()
             m.sphere_radius[s] = float(self.sphere_radius[s])
+            m.sphere_half[s][:] = np.asarray(self.sphere_half[s], float).tolist()
         for k in range(m.n_pairs):
             m.pair_a[k] = int(self.pair_a[k])
             m.pair_b[k] = int(self.pair_b[k])
@@ -285,7 +292,7 @@ class FlatModel:
     _ARRAYS = ("parent", "R0", "axis", "d", "e", "mass", "inertia", "joint_damping",
                "lower", "upper", "max_force", "max_vel", "q_init", "base_inertia",
                "base_pos0", "base_quat0", "frame_pos", "frame_quat", "sphere_link",
-               "sphere_flags", "sphere_pos", "sphere_radius", "pair_a", "pair_b",
+               "sphere_flags", "sphere_pos", "sphere_radius", "sphere_half", "pair_a", "pair_b",
                "act_joint")
     _INT = ("parent", "sphere_link", "sphere_flags", "pair_a", "pair_b", "act_joint")
 
@@ -311,14 +318,17 @@ class FlatModel:
         o = json.loads(text)
         kw = {}
         for k in FlatModel._ARRAYS:
+            if k not in o:          # files written before the field existed
+                continue
             if k in FlatModel._INT:
                 kw[k] = np.array(o[k], np.int32)
             else:
                 kw[k] = np.array(o[k], dtype=object).astype(np.float64) if len(o[k]) else np.zeros(0)
         n = len(kw["parent"])
         kw["R0"] = kw["R0"].reshape(n, 3, 3)
-        for k, w in (("sphere_pos", 3),):
-            kw[k] = kw[k].reshape(-1, w)
+        for k, w in (("sphere_pos", 3), ("sphere_half", 3)):
+            if k in kw:
+                kw[k] = kw[k].reshape(-1, w)
         return FlatModel(
             name=o["name"], base_link=o["base_link"],
             joint_names_all=o["joint_names_all"], link_names_all=o["link_names_all"],

@@ -166,49 +166,104 @@ def stl_aabb(path: str, scale: Sequence[float] = (1, 1, 1)) -> Optional[Tuple[np
     return None if verts is None else (verts.min(0), verts.max(0))
 
 
-def hull_support_points(verts: np.ndarray) -> List[np.ndarray]:
-    """Support vertices of the convex hull of ``verts`` in the 8 diagonal directions of its
-    bounding box (each direction scaled by the inverse half extents, so that a slab still
-    yields its corners), in the corner order of ``_box_spheres``; duplicates are dropped.
-    The support vertex of a hull is a vertex of the point set, so no hull is constructed."""
+GROUND_TOL = 1.5e-3       # support gap the ground-point selection aims at [m]
+BODY_MAX_PRIMITIVES = 64  # all primitives of one body: one 64-lane trip of the kernel's contact detection
+GROUND_MAX_POINTS = 56    # per collision element (one body's ground points must fit one 64-lane pass of the kernel)
+
+
+def _fixed_directions(n: int, seed: int) -> np.ndarray:
+    d = np.random.default_rng(seed).normal(size=(n, 3))
+    return d / np.linalg.norm(d, axis=1)[:, None]
+
+
+def hull_support_points(verts: np.ndarray, tol: float = GROUND_TOL, max_points: int = GROUND_MAX_POINTS) -> List[np.ndarray]:
+    """Vertices of the convex hull of ``verts`` that stand in for the hull against a PLANE: a plane with normal u touches
+    a hull at its support vertex along -u, so what matters is that for every direction some kept vertex comes within
+    ``tol`` of the hull's support.  First the support vertices along the 26 directions of the bounding box (faces, edges,
+    corners; scaled by the inverse half extents so that a slab still yields its corners), then greedily the support vertex
+    of the worst of 4000 fixed directions until the gap is <= tol (or ``max_points`` are kept).  The support vertex of a
+    hull is a vertex of the point set, so no hull needs to be constructed; duplicates are dropped."""
+    verts = np.unique(np.asarray(verts, float), axis=0)
     lo, hi = verts.min(0), verts.max(0)
     h = np.maximum(0.5 * (hi - lo), 1e-9)
     c = 0.5 * (lo + hi)
-    out: List[np.ndarray] = []
-    for sx in (-1.0, 1.0):
-        for sy in (-1.0, 1.0):
-            for sz in (-1.0, 1.0):
-                d = np.array([sx, sy, sz]) / h
-                v = verts[int(np.argmax((verts - c) @ d))]
-                if not any(np.array_equal(v, o) for o in out):
-                    out.append(v.copy())
-    return out
+    idx: List[int] = []
+    for sx in (-1.0, 0.0, 1.0):
+        for sy in (-1.0, 0.0, 1.0):
+            for sz in (-1.0, 0.0, 1.0):
+                if sx == sy == sz == 0.0:
+                    continue
+                k = int(np.argmax((verts - c) @ (np.array([sx, sy, sz]) / h)))
+                if k not in idx:
+                    idx.append(k)
+    D = _fixed_directions(4000, 1)
+    hull_sup = (verts @ D.T).max(0)
+    while len(idx) < max_points:
+        gap = hull_sup - (verts[idx] @ D.T).max(0)
+        j = int(gap.argmax())
+        if gap[j] <= tol:
+            break
+        k = int(np.argmax(verts @ D[j]))
+        if k in idx:
+            break
+        idx.append(k)
+    return [verts[k].copy() for k in idx]
 
 
-def _box_spheres(lo: np.ndarray, hi: np.ndarray, self_spheres: bool, ground_points=None):
-    """Ground points (``ground_points``, else the 8 box corners) + inscribed spheres along the longest axis (self)."""
-    out = []
-    if ground_points is not None:
-        out = [(np.asarray(p, float), 0.0, SPHERE_GROUND) for p in ground_points]
-    else:
-        for ix in (lo[0], hi[0]):
-            for iy in (lo[1], hi[1]):
-                for iz in (lo[2], hi[2]):
-                    out.append((np.array([ix, iy, iz]), 0.0, SPHERE_GROUND))
-    if self_spheres:
-        c = 0.5 * (lo + hi)
-        h = 0.5 * (hi - lo)
-        ax = int(np.argmax(h))
-        others = [k for k in range(3) if k != ax]
-        r = float(min(h[others[0]], h[others[1]]))
-        if r > 1e-4:
-            span = max(h[ax] - r, 0.0)
-            k = int(min(3, max(1, round(h[ax] / r))))
-            for j in range(k):
-                off = 0.0 if k == 1 else -span + 2.0 * span * j / (k - 1)
-                p = c.copy()
-                p[ax] += off
-                out.append((p, r, SPHERE_SELF))
+def support_gap(verts: np.ndarray, kept, n_dirs: int = 1000, seed: int = 0) -> float:
+    """Largest (hull support - best kept vertex) over ``n_dirs`` random plane normals [m]: how far a plane can sink into
+    the hull before it meets a kept vertex (tests/test_loader_and_layout.py)."""
+    D = _fixed_directions(n_dirs, seed)
+    return float(((np.asarray(verts, float) @ D.T).max(0) - (np.asarray(kept, float) @ D.T).max(0)).max())
+
+
+def fit_capsule(verts: np.ndarray):
+    """Sphere-swept segment fitted to the convex hull of ``verts`` for link-link contact: axis = the principal axis of the
+    hull's vertices through the hull centroid, extent = the hull's extent along it, radius = that of the capsule with the
+    hull's VOLUME and that extent (a sphere of the hull's volume if the hull is not elongated).
+    Returns (centre, half axis vector, radius)."""
+    from scipy.spatial import ConvexHull
+    verts = np.asarray(verts, float)
+    hull = ConvexHull(verts)
+    hv = verts[hull.vertices]
+    vol = float(hull.volume)
+    # volume centroid from the hull's triangles (fan of tetrahedra from an interior point)
+    o = hv.mean(0)
+    tri = verts[hull.simplices]
+    tv = np.abs(np.einsum("ij,ij->i", tri[:, 0] - o, np.cross(tri[:, 1] - o, tri[:, 2] - o))) / 6.0
+    cen = ((tri.sum(1) + o) / 4.0 * tv[:, None]).sum(0) / tv.sum()
+    w, V = np.linalg.eigh(np.cov((hv - cen).T))
+    ax = V[:, int(np.argmax(w))]
+    t = (hv - cen) @ ax
+    tmin, tmax = float(t.min()), float(t.max())
+    L = tmax - tmin
+    r_sphere = (3.0 * vol / (4.0 * math.pi)) ** (1.0 / 3.0)
+    if L <= 2.0 * r_sphere * 1.05:                       # not elongated: a sphere of equal volume at the centroid
+        return cen, np.zeros(3), r_sphere
+    # pi r^2 (L - 2 r) + 4/3 pi r^3 = vol, monotone in r on (0, L / 2): bisection
+    lo_r, hi_r = 0.0, 0.5 * L
+    for _ in range(60):
+        r = 0.5 * (lo_r + hi_r)
+        if math.pi * r * r * (L - 2.0 * r) + 4.0 / 3.0 * math.pi * r ** 3 < vol:
+            lo_r = r
+        else:
+            hi_r = r
+    r = 0.5 * (lo_r + hi_r)
+    mid = cen + ax * 0.5 * (tmin + tmax)
+    return mid, ax * (0.5 * L - r), r
+
+
+def _box_vertices(lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], float)
+
+
+def _element_primitives(ground_points, hull_verts):
+    """Primitives of one collision element: its ground points (radius 0) and ONE sphere-swept segment fitted to its hull
+    for link-link contact.  Each entry: (position, radius, flags, half axis)."""
+    out = [(np.asarray(p, float), 0.0, SPHERE_GROUND, np.zeros(3)) for p in ground_points]
+    c, half, r = fit_capsule(hull_verts)
+    if r > 1e-4:
+        out.append((c, float(r), SPHERE_SELF, half))
     return out
 
 
@@ -403,7 +458,7 @@ def load_urdf(path: str,
         frame_quat[b] = mat_to_quat(body_RL[b].T)
 
     # collision spheres
-    s_link, s_flag, s_pos, s_rad = [], [], [], []
+    s_link, s_flag, s_pos, s_rad, s_half = [], [], [], [], []
     missing_meshes = []
     for ln, (b, R, t) in link_body.items():
         for xyz, Rc, g in links[ln]["collisions"]:
@@ -412,35 +467,42 @@ def load_urdf(path: str,
                 continue
             mesh, box, sph, cyl = g.find("mesh"), g.find("box"), g.find("sphere"), g.find("cylinder")
             if mesh is not None:
-                bounds, pts = None, None
-                if mesh_aabbs and ln in mesh_aabbs:
-                    bounds = (np.array(mesh_aabbs[ln][0], float), np.array(mesh_aabbs[ln][1], float))
+                verts = None
+                if mesh_aabbs and ln in mesh_aabbs:          # only bounds are known: the box stands in for the hull
+                    verts = _box_vertices(np.array(mesh_aabbs[ln][0], float), np.array(mesh_aabbs[ln][1], float))
+                    shapes = _element_primitives(verts, verts)
                 else:
                     fn = mesh.get("filename").replace("package://", "")
                     verts = stl_vertices(os.path.join(urdf_dir, fn), _floats(mesh.get("scale"), 3, 1.0))
                     if verts is not None:
-                        bounds = (verts.min(0), verts.max(0))
-                        pts = hull_support_points(verts)
-                if bounds is None:
+                        shapes = _element_primitives(hull_support_points(verts), verts)
+                if verts is None:
                     missing_meshes.append(ln)
                     continue
-                shapes = _box_spheres(bounds[0], bounds[1], True, pts)
             elif box is not None:
                 h = 0.5 * np.array(_floats(box.get("size"), 3))
-                shapes = _box_spheres(-h, h, True)
+                verts = _box_vertices(-h, h)
+                shapes = _element_primitives(verts, verts)
             elif sph is not None:
-                shapes = [(np.zeros(3), float(sph.get("radius")), SPHERE_GROUND | SPHERE_SELF)]
+                shapes = [(np.zeros(3), float(sph.get("radius")), SPHERE_GROUND | SPHERE_SELF, np.zeros(3))]
             elif cyl is not None:
+                # a cylinder is taken as the capsule of the same radius and overall length: one segment for link-link
+                # contact, its two end spheres (and the middle one of a long cylinder) against the ground
                 r, L = float(cyl.get("radius")), float(cyl.get("length"))
                 half = max(0.5 * L - r, 0.0)
-                zs = [0.0] if half == 0.0 else ([-half, half] if half < 2 * r else [-half, 0.0, half])
-                shapes = [(np.array([0, 0, z]), r, SPHERE_GROUND | SPHERE_SELF) for z in zs]
-            for p, r, fl in shapes:
+                if half == 0.0:
+                    shapes = [(np.zeros(3), r, SPHERE_GROUND | SPHERE_SELF, np.zeros(3))]
+                else:
+                    zs = [-half, half] if half < 2 * r else [-half, 0.0, half]
+                    shapes = [(np.array([0, 0, z]), r, SPHERE_GROUND, np.zeros(3)) for z in zs]
+                    shapes.append((np.zeros(3), r, SPHERE_SELF, np.array([0.0, 0.0, half])))
+            for p, r, fl, hv in shapes:
                 p_car = R @ (Rc @ p + xyz) + t
                 s_link.append(b)
                 s_flag.append(fl)
                 s_pos.append(body_RL[b + 1].T @ (p_car - body_com[b + 1]))
                 s_rad.append(r)
+                s_half.append(body_RL[b + 1].T @ (R @ (Rc @ hv)))
 
     # A body's spheres must be contiguous (the "4 deepest points per body" rule ranks inside one run, and
     # hg_create verifies it).  link_body is in link-DFS order, so a carrier link whose welded (fixed-joint)
@@ -452,6 +514,28 @@ def load_urdf(path: str,
         s_flag = [s_flag[k] for k in order]
         s_pos = [s_pos[k] for k in order]
         s_rad = [s_rad[k] for k in order]
+        s_half = [s_half[k] for k in order]
+
+        # one body's primitives must fit one 64-lane trip of the kernel (hg_sim.hip build_dev_model): a body welded from
+        # many meshes keeps the hull support points of the union of its ground points
+        keep = np.ones(len(s_link), bool)
+        for b in sorted(set(s_link)):
+            idx = [k for k in range(len(s_link)) if s_link[k] == b]
+            if len(idx) <= BODY_MAX_PRIMITIVES:
+                continue
+            pts = [k for k in idx if s_flag[k] == SPHERE_GROUND and s_rad[k] == 0.0]
+            room = BODY_MAX_PRIMITIVES - (len(idx) - len(pts))
+            if room < 8:
+                raise ValueError(f"body {b}: {len(idx) - len(pts)} collision primitives besides hull points; at most {BODY_MAX_PRIMITIVES} fit")
+            P = np.array([s_pos[k] for k in pts])
+            chosen = hull_support_points(P, GROUND_TOL, room)
+            chosen_set = {tuple(np.round(c, 12)) for c in chosen}
+            for k in pts:
+                keep[k] = tuple(np.round(s_pos[k], 12)) in chosen_set
+        if not keep.all():
+            sel = [k for k in range(len(s_link)) if keep[k]]
+            s_link = [s_link[k] for k in sel]; s_flag = [s_flag[k] for k in sel]; s_pos = [s_pos[k] for k in sel]
+            s_rad = [s_rad[k] for k in sel]; s_half = [s_half[k] for k in sel]
 
     # self-collision pairs: different bodies, neither an ancestor of the other
     # (URDF_USE_SELF_COLLISION_EXCLUDE_ALL_PARENTS, dancer_env.py:60)
@@ -506,6 +590,7 @@ def load_urdf(path: str,
         frame_pos=frame_pos, frame_quat=frame_quat,
         sphere_link=np.array(s_link, np.int32), sphere_flags=np.array(s_flag, np.int32),
         sphere_pos=np.array(s_pos, float).reshape(-1, 3), sphere_radius=np.array(s_rad, float),
+        sphere_half=np.array(s_half, float).reshape(-1, 3),
         pair_a=np.array(pair_a, np.int32), pair_b=np.array(pair_b, np.int32),
         act_joint=np.arange(n, dtype=np.int32),
         meta={"missing_meshes": missing_meshes,

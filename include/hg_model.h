@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define HG_MAX_LINKS    62   /* moving links == joint dofs (one lane each, plus the base; 64-bit link masks) */
-#define HG_MAX_SPHERES  192  /* collision spheres (radius may be 0 = point)        */
+#define HG_MAX_SPHERES  1024 /* collision primitives: points (radius 0), spheres, sphere-swept segments */
 #define HG_MAX_PAIRS    1024 /* self-collision sphere pairs                        */
 #define HG_MAX_CONTACTS 12   /* contact slots per env per physics step             */
 #define HG_MAX_ROWS     128  /* n_links + 3*max_contacts: one row per lane up to 64, two per lane beyond   */
@@ -88,6 +88,9 @@ typedef struct hg_model {
                                               bit1: takes part in self-collision pairs */
     double  sphere_pos[HG_MAX_SPHERES][3];
     double  sphere_radius[HG_MAX_SPHERES];
+    double  sphere_half[HG_MAX_SPHERES][3];/* half axis of a sphere-swept segment (capsule): the primitive is the set of points
+                                              within `radius` of the segment pos -+ half; 0 = a sphere.  Segments take part
+                                              in link-link pairs only (bit1); ground points / spheres have half = 0        */
 
     /* self-collision candidate pairs (indices into the sphere arrays) */
     int32_t pair_a[HG_MAX_PAIRS];

@@ -45,7 +45,7 @@ const char *hg_last_error(void);
 /* Library/ABI version, bumped on any signature or struct-layout change (3: hg_model.joint_limited,
  * hg_config.max_coord_velocity / enable_limits / limit_max_impulse, hg_stats_flush, hg_set_base_velocity;
  * 4: hg_get_joint_torques; 5: HG_MAX_LINKS 48 -> 62 (hg_model layout), hg_stats_accumulate_noalloc;
- * 6: hg_config.residual_threshold / store_torques).  A binding must compare it with the version its struct mirrors
+ * 6: hg_config.residual_threshold / store_torques; 7: hg_model.sphere_half, HG_MAX_SPHERES 1024).  A binding must compare it with the version its struct mirrors
  * were written for before it hands a struct to the library (humanoid_gym_amd/_capi.py does). */
 int hg_abi_version(void);
 

@@ -435,14 +435,44 @@ typedef struct {
     double pt[3], n[3], dist;
 } contact_t;
 
+/* Closest points of two sphere-swept segments (capsules; a sphere is a segment of length 0): centres ca, cb, half axes
+ * ha, hb (world), on the segments p + s d, s in [0, 1] (Ericson, Real-Time Collision Detection 5.1.9, for the exact
+ * solution).  Two nearly parallel segments have a whole interval of (nearly) closest points and the exact solution jumps
+ * between its ends with the sign of a tiny angle: a contact point that does so makes two bodies chatter.  So the
+ * parameter on a is blended from the centre of the overlap interval (parallel) to the exact solution (sin^2 of the angle
+ * >= HG_SEG_BLEND), which is continuous in the pose; the point on b is then the closest to that point, and the point on a
+ * the closest to the point on b -- for non-parallel segments exactly Ericson's result.  Writes the closest points c1 (on
+ * a), c2 (on b).  The kernel (hg_step.hip, contact detection) runs the same formulas in float32. */
+#define HG_SEG_EPS 1e-12
+#define HG_SEG_BLEND 0.03
+static double clamp01(double x) { return x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x); }
+static void seg_seg_closest(const double *ca, const double *ha, const double *cb, const double *hb, double *c1, double *c2) {
+    double p1[3], p2[3], d1[3], d2[3], r[3];
+    for (int k = 0; k < 3; k++) { p1[k] = ca[k] - ha[k]; d1[k] = 2.0 * ha[k]; p2[k] = cb[k] - hb[k]; d2[k] = 2.0 * hb[k]; r[k] = p1[k] - p2[k]; }
+    const double a = v3_dot(d1, d1), e = v3_dot(d2, d2), f = v3_dot(d2, r), c = v3_dot(d1, r), b = v3_dot(d1, d2);
+    const double ia = a > HG_SEG_EPS ? 1.0 / a : 0.0, ie = e > HG_SEG_EPS ? 1.0 / e : 0.0;
+    double nx[3], rx[3];
+    v3_cross(d1, d2, nx); v3_cross(r, d2, rx);
+    const double ae = a * e, denom = v3_dot(nx, nx);      /* = a e - b^2, without its cancellation */
+    const double w = denom < HG_SEG_BLEND * ae ? denom / (HG_SEG_BLEND * ae) : 1.0;      /* ae == 0: 1 (no axis, no blend) */
+    const double s_exact = denom > 0.0 ? clamp01(-v3_dot(rx, nx) / denom) : 0.0;         /* = (b f - c e) / denom */
+    const double sb0 = -c * ia, sb1 = (b - c) * ia;                                      /* the ends of b projected on a */
+    const double s_mid = 0.5 * (clamp01(sb0 < sb1 ? sb0 : sb1) + clamp01(sb0 < sb1 ? sb1 : sb0));
+    double s = s_mid + w * (s_exact - s_mid);
+    const double t = clamp01((b * s + f) * ie);
+    s = clamp01((b * t - c) * ia);
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k] + d1[k] * s; c2[k] = p2[k] + d2[k] * t; }
+}
+
 static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_t *w, contact_t *out) {
     int nc = 0;
     const int maxc = c->max_contacts < HG_MAX_CONTACTS ? c->max_contacts : HG_MAX_CONTACTS;
-    double cw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
+    static _Thread_local double cw[HG_MAX_SPHERES][3], hw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
     for (int s = 0; s < m->n_spheres; s++) {
         const int b = m->sphere_link[s] + 1;
         double t[3];
         m3_mulv(w->Rw[b], m->sphere_pos[s], t);
+        m3_mulv(w->Rw[b], m->sphere_half[s], hw[s]);
         HGO_FLOPS(4);
         for (int k = 0; k < 3; k++) cw[s][k] = w->xw[b][k] + t[k];
         if (hgo_noise_eps > 0) for (int k = 0; k < 3; k++) cw[s][k] += 0.3 * (noise_factor() - 1.0);
@@ -469,8 +499,10 @@ static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_
     if (c->enable_self) {
         for (int p = 0; p < m->n_pairs && nc < maxc; p++) {
             const int a = m->pair_a[p], b = m->pair_b[p];
-            double d[3] = {cw[a][0] - cw[b][0], cw[a][1] - cw[b][1], cw[a][2] - cw[b][2]};
-            HGO_FLOPS(3 + 1 + 2);
+            double c1[3], c2[3];
+            seg_seg_closest(cw[a], hw[a], cw[b], hw[b], c1, c2);
+            double d[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+            HGO_FLOPS(60 + 3 + 1 + 2);
             const double len = sqrt(v3_dot(d, d));
             const double ds = len - m->sphere_radius[a] - m->sphere_radius[b];
             if (!(ds < c->contact_margin) || len < 1e-9) continue;
@@ -479,7 +511,7 @@ static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_
             k->body_a = m->sphere_link[a]; k->body_b = m->sphere_link[b]; k->sphere_a = a; k->sphere_b = b;
             for (int j = 0; j < 3; j++) {
                 k->n[j] = d[j] / len;
-                k->pt[j] = 0.5 * ((cw[a][j] - m->sphere_radius[a] * k->n[j]) + (cw[b][j] + m->sphere_radius[b] * k->n[j]));
+                k->pt[j] = 0.5 * ((c1[j] - m->sphere_radius[a] * k->n[j]) + (c2[j] + m->sphere_radius[b] * k->n[j]));
             }
             k->dist = ds;
         }
@@ -928,13 +960,14 @@ void hgo_energy_momentum(const hg_model *m, const hg_config *c, const double *st
  */
 void hgo_contact_slack(const hg_model *m, const hg_config *c, const double *state, double *out2) {
     static _Thread_local scratch_t W;
-    double cw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
+    static _Thread_local double cw[HG_MAX_SPHERES][3], hw[HG_MAX_SPHERES][3], dist[HG_MAX_SPHERES];
     kinematics(m, state, &W);
     out2[0] = 1e30; out2[1] = 1e30;
     for (int s = 0; s < m->n_spheres; s++) {
         const int b = m->sphere_link[s] + 1;
         double t[3];
         m3_mulv(W.Rw[b], m->sphere_pos[s], t);
+        m3_mulv(W.Rw[b], m->sphere_half[s], hw[s]);
         for (int k = 0; k < 3; k++) cw[s][k] = W.xw[b][k] + t[k];
         dist[s] = cw[s][2] - m->sphere_radius[s];
         if (c->enable_ground && (m->sphere_flags[s] & 1)) {
@@ -946,7 +979,7 @@ void hgo_contact_slack(const hg_model *m, const hg_config *c, const double *stat
         for (int s = 0; s < m->n_spheres; s++) {
             if (!(m->sphere_flags[s] & 1) || !(dist[s] < c->contact_margin)) continue;
             /* in-margin distances of this sphere's body, sorted: gap between ranks 3 and 4 (0-based) */
-            double d[HG_MAX_SPHERES]; int k = 0;
+            static _Thread_local double d[HG_MAX_SPHERES]; int k = 0;
             for (int o = 0; o < m->n_spheres; o++)
                 if (m->sphere_link[o] == m->sphere_link[s] && (m->sphere_flags[o] & 1) && dist[o] < c->contact_margin) d[k++] = dist[o];
             if (k <= 4) continue;
@@ -956,7 +989,9 @@ void hgo_contact_slack(const hg_model *m, const hg_config *c, const double *stat
     if (c->enable_self)
         for (int p = 0; p < m->n_pairs; p++) {
             const int a = m->pair_a[p], b = m->pair_b[p];
-            double dd[3] = {cw[a][0] - cw[b][0], cw[a][1] - cw[b][1], cw[a][2] - cw[b][2]};
+            double c1[3], c2[3];
+            seg_seg_closest(cw[a], hw[a], cw[b], hw[b], c1, c2);
+            double dd[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
             const double ds = sqrt(v3_dot(dd, dd)) - m->sphere_radius[a] - m->sphere_radius[b];
             const double g = fabs(ds - c->contact_margin);
             if (g < out2[0]) out2[0] = g;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert getattr(L, n) is not None
     from humanoid_gym_amd._capi import HG_ABI_VERSION
-    assert L.hg_abi_version() == HG_ABI_VERSION == 6
+    assert L.hg_abi_version() == HG_ABI_VERSION == 7
 
 
 def test_struct_sizes_match_header():
@@ -282,7 +282,7 @@ def test_hg_create_rejects_numbers_the_step_cannot_use():
     assert b"unit quaternion" in rejected(put("base_quat0", 3, 2.0))
     assert b"lower <= upper" in rejected(lambda cm: (cm.lower.__setitem__(1, 1.0), cm.upper.__setitem__(1, -1.0)))
     assert b"bounds must be >= 0" in rejected(put("max_force", 4, -1.0))
-    assert b"sphere" in rejected(put("sphere_radius", 0, float("nan")))
+    assert b"collision primitive" in rejected(put("sphere_radius", 0, float("nan")))
     assert b"frame constants" in rejected(put("d", 7, float("inf"), 2))
     assert b"config" in rejected(edit_cfg=lambda cc: setattr(cc, "friction", float("nan")))
     assert b"config" in rejected(edit_cfg=lambda cc: cc.gravity.__setitem__(2, float("inf")))

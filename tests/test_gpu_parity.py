@@ -317,6 +317,8 @@ def test_dancer_self_collision_rows():
             assert worst.max() < 1e-3
         same += int(sum(np.array_equal(p[e], o["pairs"][e]) for e in range(n_envs)))
         saw_self |= bool(((p[..., 1] >= 0) & (p[..., 0] >= 0)).any())
+        if t == 0:      # the feet (links 11, 17) overlap at q = 0
+            assert set(map(tuple, o["pairs"][0, :o["n_contacts"][0]].tolist())) >= {(11, 17)}
     # Free-running FP32 and FP64 trajectories of a robot standing on deeply overlapping foot spheres separate
     # (ill-conditioned contact normals), so no joint-angle bound is asserted for the free run beyond the first
     # 12 steps above: the parity statement is the one-step comparison from shared states below.
@@ -326,7 +328,7 @@ def test_dancer_self_collision_rows():
     # worst env over the 100 steps; a kernel that is wrong, not merely float32, separates at once and everywhere
     assert same >= 0.9 * 100 * n_envs and worst.max() < 0.15 and np.median(worst) < 5e-3
     assert saw_self
-    assert set(map(tuple, o["pairs"][0, :o["n_contacts"][0]].tolist())) >= {(11, 17)}
+    assert any(b >= 0 for _, b in o["pairs"][0, :o["n_contacts"][0]].tolist())      # link-link contacts at the end too (hips, legs)
     st = gpu.get_state().cpu().numpy()
     assert np.isfinite(st).all() and np.abs(st[:, :3] - cpu.state[:, :3]).max() < 2e-2
 

@@ -1,5 +1,6 @@
 """Integer half of the contract: joint/link index maps, topology, name lists (bit-exact)."""
 import json
+import math
 import os
 
 import numpy as np
@@ -49,7 +50,7 @@ def test_dancer_axes_and_reset_pose():
     com = (m.base_mass * xb + sum(m.mass[i] * xw[i] for i in range(n))) / m.total_mass()
     assert np.abs(com - np.array(GOLD["reset_com"])).max() < 1e-4
     zs = [((xb if b < 0 else xw[b]) + (Rb if b < 0 else Rw[b]) @ m.sphere_pos[s])[2] - m.sphere_radius[s]
-          for s, b in enumerate(m.sphere_link)]
+          for s, b in enumerate(m.sphere_link) if m.sphere_flags[s] & 1]      # the points tested against the plane
     assert abs(min(zs) - GOLD["reset_lowest_z"]) < 1e-4
     # base link frame sits where loadURDF was told to put it (dancer_env.py:59)
     Rl = Rb @ quat_to_mat(m.frame_quat[0])
@@ -148,48 +149,76 @@ def test_mimic_tags_are_recorded(tmp_path):
 
 
 def test_hull_support_points_are_vertices_of_the_point_set():
-    """Mesh collision geometry: ground points are support vertices of the mesh's convex hull
-    in the 8 bounding-box diagonals -- members of the vertex set, equal to the corners for a box, and
-    strictly inside the bounding box for a rounded body."""
-    from humanoid_gym_amd.urdf import hull_support_points
+    """Mesh collision geometry: ground points are vertices of the mesh's convex hull chosen so that a plane
+    of ANY orientation meets a kept vertex within GROUND_TOL of where it would meet the hull -- members of the vertex
+    set, exactly the corners for a box, and strictly inside the bounding box for a rounded body."""
+    from humanoid_gym_amd.urdf import hull_support_points, support_gap, GROUND_TOL, GROUND_MAX_POINTS
     rng = np.random.default_rng(5)
     box = np.array([[x, y, z] for x in (-0.1, 0.2) for y in (-0.3, 0.05) for z in (0.0, 0.02)])
     cloud = np.vstack([box, box.mean(0) + 0.3 * (rng.random((200, 3)) - 0.5) * (box.max(0) - box.min(0))])
     pts = hull_support_points(cloud)
-    assert len(pts) == 8 and np.abs(np.array(pts) - box).max() == 0.0       # corner order of the box enumeration
+    assert len(pts) == 8 and {tuple(p) for p in pts} == {tuple(p) for p in box}
+    assert support_gap(cloud, pts) < 1e-12
     ball = rng.normal(size=(500, 3))
     ball = 0.05 * ball / np.linalg.norm(ball, axis=1, keepdims=True) * np.array([1.0, 2.0, 0.5])
     pts = np.array(hull_support_points(ball))
-    assert all(any(np.array_equal(p, v) for v in ball) for p in pts)
+    assert all(any(np.array_equal(p, v) for v in ball) for p in pts) and len(pts) <= GROUND_MAX_POINTS
     lo, hi = ball.min(0), ball.max(0)
     corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
-    assert np.linalg.norm(pts - corners, axis=1).min() > 0.01                 # an ellipsoid has no corners
+    assert np.linalg.norm(pts[:, None] - corners[None], axis=2).min() > 0.01    # an ellipsoid has no corners
+    # the greedy rule: more points, smaller gap (fresh directions, not the 4000 the selection used), monotonically
+    gaps = [support_gap(ball, hull_support_points(ball, tol=0.0, max_points=k)) for k in (8, 16, 32, 56)]
+    assert all(a >= b for a, b in zip(gaps, gaps[1:])) and gaps[-1] < 0.5 * gaps[0]
     octa = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float)
-    assert 1 <= len(hull_support_points(octa)) <= 6                          # duplicates are dropped
+    assert len(hull_support_points(octa)) == 6 and len(hull_support_points(np.vstack([octa, octa]))) == 6   # duplicates are dropped
+
+
+def test_capsule_fit_and_segment_distance():
+    """Link-link geometry: one sphere-swept segment per collision element, fitted to the element's convex hull (axis =
+    principal axis through the volume centroid, extent = the hull's, radius = equal volume); a box 2 x 2 x 10 gives
+    the capsule along z, a cube gives the sphere of its volume."""
+    from humanoid_gym_amd.urdf import fit_capsule, _box_vertices
+    c, h, r = fit_capsule(_box_vertices(np.array([-1.0, -1.0, -5.0]) + 3.0, np.array([1.0, 1.0, 5.0]) + 3.0))
+    assert np.abs(c - 3.0).max() < 1e-9 and np.abs(np.abs(h) - [0, 0, 5.0 - r]).max() < 1e-9
+    vol = math.pi * r * r * 2 * np.linalg.norm(h) + 4.0 / 3.0 * math.pi * r ** 3
+    assert abs(vol - 40.0) < 1e-6 and 1.0 < r < math.sqrt(2.0)                   # between the inscribed and the circumscribed radius
+    c, h, r = fit_capsule(_box_vertices(-np.ones(3), np.ones(3)))
+    assert np.abs(h).max() == 0.0 and abs(4.0 / 3.0 * math.pi * r ** 3 - 8.0) < 1e-9
 
 
 def test_dancer_ground_points_come_from_the_reference_meshes():
-    """With the reference tree present: every ground point of the shipped Dancer model is a vertex of
-    that link's STL (in the URDF link frame); always: 8 or fewer per link, contiguous per body."""
+    """With the reference tree present: every ground point of the shipped Dancer model is a vertex of that link's STL
+    (in the URDF link frame), and a plane of any orientation (1000 random normals per link) meets a kept vertex within
+    2 mm of where it would meet the link's convex hull -- against 5.8 - 29.5 mm for the 8 bounding-box diagonals the
+    model used before (the figures are printed by tools/geometry_report.py).  Always: at most 56
+    points per link, contiguous per body, one link-link primitive per link."""
     import os
-    from humanoid_gym_amd.urdf import stl_vertices
+    from humanoid_gym_amd.urdf import stl_vertices, support_gap, GROUND_MAX_POINTS
     m, _ = load_robot("dancer")
-    ground = [s for s in range(len(m.sphere_link)) if m.sphere_radius[s] == 0.0]
+    ground = [s for s in range(len(m.sphere_link)) if m.sphere_flags[s] & 1]
+    assert all(m.sphere_radius[s] == 0.0 and np.abs(m.sphere_half[s]).max() == 0.0 for s in ground)
     per_link = {}
     for s in ground:
         per_link.setdefault(int(m.sphere_link[s]), []).append(s)
-    assert len(per_link) == 18 and all(1 <= len(v) <= 8 for v in per_link.values())
+    assert len(per_link) == 18 and all(8 <= len(v) <= GROUND_MAX_POINTS for v in per_link.values())
+    selfp = [s for s in range(len(m.sphere_link)) if m.sphere_flags[s] & 2]
+    assert sorted(int(m.sphere_link[s]) for s in selfp) == sorted(per_link) and all(m.sphere_radius[s] > 0.005 for s in selfp)
     mesh_dir = "/root/reference/humanoid_gym/envs/assets/dancer/meshes"
     if not os.path.isdir(mesh_dir):
         pytest.skip("reference meshes not on this machine")
+    worst = 0.0
     for b, idx in per_link.items():
         verts = stl_vertices(os.path.join(mesh_dir, m.link_names_all[b] + ".STL"))
         assert verts is not None, m.link_names_all[b]
         # internal (COM, principal axes) frame -> URDF link frame
         R = quat_to_mat(m.frame_quat[b + 1])
-        for s in idx:
-            p_link = R.T @ (m.sphere_pos[s] - m.frame_pos[b + 1])
-            assert np.abs(verts - p_link).sum(1).min() < 1e-6, (m.link_names_all[b], s)
+        kept = np.array([R.T @ (m.sphere_pos[s] - m.frame_pos[b + 1]) for s in idx])
+        for p_link in kept:
+            assert np.abs(verts - p_link).sum(1).min() < 1e-6, m.link_names_all[b]
+        gap = support_gap(verts, kept, n_dirs=1000, seed=123 + b)
+        assert gap <= 2e-3, (m.link_names_all[b], gap)
+        worst = max(worst, gap)
+    assert worst > 0.0
 
 
 def test_welded_child_after_revolute_sibling_keeps_a_bodys_spheres_contiguous(tmp_path):
