@@ -232,6 +232,8 @@ def main():
         setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
     n_envs = args.envs_per_gpu
     is_nao = args.robot in ("nao", "nao_hands")
+    if is_nao and not any(kv.startswith("store_torques=") for kv in args.cfg):
+        cfg.store_torques = False      # as NaoEnv (envs/softbank_envs.py): nothing on this path reads getJointState()[3]
     if is_nao:
         rows, sel = synthetic_replay(model)
         if args.robot == "nao_hands":
@@ -369,6 +371,7 @@ def main():
     if args.robot == "nao_hands" and not args.cfg and world == 1 and os.environ.get("HG_BENCH_SMALL", "1") != "0":
         try:
             hmodel, hcfg = load_robot("nao")
+            hcfg.store_torques = cfg.store_torques
             hrows, hsel = synthetic_replay(hmodel)
             hsim = HgSim(hmodel, hcfg, n_envs, dev)
             hrows_d = torch.tensor(hrows, device=dev)
@@ -422,7 +425,7 @@ def main():
                        if is_nao else f"{args.robot} random targets",
                        "robot": model.name + ("_like (stand-in URDF" + (", with the finger joints of the hands" if args.robot.endswith("_hands") else "") + ")" if args.robot != "dancer" else ""),
                        "constraint_rows": model.n_links + 3 * cfg.max_contacts, "action_columns": int(len(sel)),
-                       "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters,
+                       "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters, "motor_torques_stored": bool(cfg.store_torques),
                        "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -31,6 +31,10 @@ class _SoftbankEnv(BatchedHumanoidEnv):
         if hands is None:
             hands = self.ROBOT in ("nao", "romeo") and urdf_path is None
         model, cfg = load_robot(self.ROBOT, urdf_path, hands=hands)
+        # qibullet's robots are read through getAnglesPosition / getAnglesVelocity (nao_env.py:73, pepper_env.py:64): no
+        # caller of these envs reads getJointState()[3], so the step does not store the motor torques (4 n bytes per env
+        # and physics step less written); store_torques=True as an override brings sim.joint_torques() back
+        cfg.store_torques = False
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)
         super().__init__(model, cfg, n_envs, device, n_substeps, auto_reset)

@@ -464,6 +464,11 @@ static void seg_seg_closest(const double *ca, const double *ha, const double *cb
     for (int k = 0; k < 3; k++) { c1[k] = p1[k] + d1[k] * s; c2[k] = p2[k] + d2[k] * t; }
 }
 
+/* test hook (tests/test_oracle_physics.py): the closest points of two sphere-swept segments as the step computes them */
+void hgo_seg_seg_closest(const double *ca, const double *ha, const double *cb, const double *hb, double *c1, double *c2) {
+    seg_seg_closest(ca, ha, cb, hb, c1, c2);
+}
+
 static int detect_contacts(const hg_model *m, const hg_config *c, const scratch_t *w, contact_t *out) {
     int nc = 0;
     const int maxc = c->max_contacts < HG_MAX_CONTACTS ? c->max_contacts : HG_MAX_CONTACTS;

@@ -58,6 +58,8 @@ def lib():
         L.hgo_energy_momentum.restype = None
         L.hgo_contact_slack.argtypes = [C.POINTER(HgModel), C.POINTER(HgConfig), dp, dp]
         L.hgo_contact_slack.restype = None
+        L.hgo_seg_seg_closest.argtypes = [dp] * 6
+        L.hgo_seg_seg_closest.restype = None
         L.hgo_kinematics.argtypes = [C.POINTER(HgModel), dp, dp, dp]
         L.hgo_kinematics.restype = None
         L.hgo_set_row_noise.argtypes = [C.c_double, C.c_uint64]
@@ -240,3 +242,11 @@ class OracleSim:
         st = np.ascontiguousarray(self.state[env])
         lib().hgo_kinematics(C.byref(self.cm), _dp(st), _dp(Rw), _dp(xw))
         return Rw, xw
+
+
+def seg_seg_closest(ca, ha, cb, hb):
+    """Closest points (on a, on b) of two sphere-swept segments (centre, half axis) as oracle/hg_oracle.c computes them."""
+    a = [np.ascontiguousarray(x, np.float64) for x in (ca, ha, cb, hb)]
+    c1, c2 = np.zeros(3), np.zeros(3)
+    lib().hgo_seg_seg_closest(*[_dp(x) for x in a], _dp(c1), _dp(c2))
+    return c1, c2

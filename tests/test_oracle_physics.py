@@ -280,3 +280,51 @@ def test_vanishing_contact_row_is_disabled(tmp_path):
         o = sim.step(None)
         assert o["n_contacts"][0] == 1 and o["pairs"][0][0].tolist() == [0, 2]
     assert np.abs(sim.qd).max() == 0.0 and np.abs(sim.state[0, 7:13]).max() == 0.0
+
+
+def test_segment_segment_closest_points():
+    """Link-link primitives are sphere-swept segments (oracle/hg_oracle.c seg_seg_closest, hg_math.h on the device).  Away
+    from parallel the closest points are the exact ones (brute force over both parameters); two parallel segments give the
+    CENTRE of their overlap; and the contact point is continuous through the parallel configuration (the exact solution
+    jumps from one end of the overlap to the other there, which made Dancer's feet chatter)."""
+    from _oracle import seg_seg_closest
+    rng = np.random.default_rng(3)
+    g = np.linspace(-1.0, 1.0, 401)
+    n_exact = 0
+    for _ in range(300):
+        ca, cb = rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.2, 0.2, 3)
+        ha, hb = rng.normal(size=3) * rng.uniform(0.0, 0.1), rng.normal(size=3) * rng.uniform(0.0, 0.1)
+        if rng.random() < 0.2:
+            ha = np.zeros(3)                     # a sphere
+        if rng.random() < 0.2:
+            hb = np.zeros(3)
+        c1, c2 = seg_seg_closest(ca, ha, cb, hb)
+        # the points lie on their segments
+        for c, cc, h in ((c1, ca, ha), (c2, cb, hb)):
+            if h @ h > 0:
+                u = (c - cc) @ h / (h @ h)
+                assert -1 - 1e-12 <= u <= 1 + 1e-12 and np.abs(cc + u * h - c).max() < 1e-12
+            else:
+                assert np.abs(c - cc).max() < 1e-15
+        sin2 = 1.0 if not (ha @ ha > 0 and hb @ hb > 0) else 1.0 - (ha @ hb) ** 2 / ((ha @ ha) * (hb @ hb))
+        if sin2 >= 0.03:                         # no blending: the exact minimum
+            P, Q = ca + g[:, None] * ha, cb + g[:, None] * hb
+            brute = np.sqrt(((P[:, None, :] - Q[None, :, :]) ** 2).sum(2)).min()
+            assert np.linalg.norm(c1 - c2) <= brute + 1e-12
+            assert np.linalg.norm(c1 - c2) >= brute - 2e-3 * (np.linalg.norm(ha) + np.linalg.norm(hb))      # the grid's resolution
+            n_exact += 1
+    assert n_exact > 150
+    # parallel, overlapping halfway: the centre of the overlap, on both
+    c1, c2 = seg_seg_closest([0, 0, 0], [0.1, 0, 0], [0.1, 0.05, 0], [0.1, 0, 0])
+    assert np.abs(c1 - [0.05, 0, 0]).max() < 1e-12 and np.abs(c2 - [0.05, 0.05, 0]).max() < 1e-12
+    # parallel, no overlap: the facing ends
+    c1, c2 = seg_seg_closest([0, 0, 0], [0.1, 0, 0], [0.5, 0.05, 0], [0.1, 0, 0])
+    assert np.abs(c1 - [0.1, 0, 0]).max() < 1e-12 and np.abs(c2 - [0.4, 0.05, 0]).max() < 1e-12
+    # continuity through parallel: tilt b by -+ a small angle about z; the exact closest point on a jumps between x = -+0.1
+    prev = None
+    for ang in np.linspace(-0.02, 0.02, 41):
+        c1, _ = seg_seg_closest([0, 0, 0], [0.1, 0, 0], [0, 0.05, 0], [0.1 * np.cos(ang), 0.1 * np.sin(ang), 0])
+        if prev is not None:
+            assert np.abs(c1 - prev).max() < 0.01
+        prev = c1
+    assert np.abs(seg_seg_closest([0, 0, 0], [0.1, 0, 0], [0, 0.05, 0], [0.1, 0, 0])[0]).max() < 1e-12

@@ -206,7 +206,18 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                                     "%.3g rad, %.3g rad/s, torque %.3g" % worst))
                     continue
                 if int_why is not None:
-                    fail(e, t, int_why + f" (oracle under input noise: {sens:.3g} of the tolerance)", before, o, gq)
+                    # several substeps: the contact set of the LAST substep belongs to the state the earlier ones left.  Where the
+                    # oracle's own answer moves by more than the tolerances under float32-sized noise INSIDE its step (rows, sphere
+                    # centres: hgo_set_row_noise), the two arithmetics legitimately enter the last substep in different states.
+                    sp = walk.noise_spread(before[e], act[e], joint_sel=sel, n_substeps=sub,
+                                           base_cmd_row=None if base_cmd is None else base_cmd[e], trials=64)
+                    inner = max(float(np.max(sp["q"])) / fp.tol[0], float(np.max(sp["qd"])) / fp.tol[1])
+                    if inner > 1.0 or not sp["same_contacts"]:
+                        ip.total -= 1
+                        tot.ill.append((tag.split(":")[0], nce, "%.3g rad, %.3g rad/s, torque %.3g" % vals, " and another contact set",
+                                        "internal noise: %.3g rad, %.3g rad/s" % (float(np.max(sp["q"])), float(np.max(sp["qd"])))))
+                        continue
+                    fail(e, t, int_why + f" (oracle under input noise: {sens:.3g} of the tolerance, under internal noise: {inner:.3g})", before, o, gq)
             if identical:
                 n_out = len(fp.outliers)
                 spread = None
