@@ -239,6 +239,9 @@ void stats_final_kernel(const float *__restrict__ part, int n_slots, float *__re
 
 }  // namespace hg
 
+#define HG_LDS_PER_CU  (160 * 1024)   // gfx950
+#define HG_LDS_GRANULE 1280           // LDS is handed out in blocks of this size
+
 // ---------------------------------------------------------------------------------------
 // the handle
 // ---------------------------------------------------------------------------------------
@@ -250,6 +253,7 @@ struct hg_sim {
     int n_spheres = 0, n_pairs = 0, maxlev = 0, n_base_children = 0, n_self = 0;
     int8_t lev_start[hg::DMAX + 4]{};
     int lds_bytes = 0;
+    int waves_per_cu = 16;      // resident waves (envs) per CU: 4 SIMDs x the variant's waves per SIMD, or fewer (hg_create)
     int n_cu = 256;             // compute units of the device (MI355X: 256)
     hg_config cfg{};
     int32_t act_joint[HG_MAX_LINKS]{};
@@ -550,6 +554,19 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
                                                        ys_floats(kVariants[variant].nmx, kVariants[variant].maxc, kVariants[variant].depth),
                                                        cache_stride(kVariants[variant].nmx)).total;
 
+    s->waves_per_cu = 4 * kVariants[variant].wpe;
+    {   // ... or what LDS admits (NAO with fingers: 16.1 KB per wave = 9 per CU where the registers would admit 12)
+        const int by_lds = HG_LDS_PER_CU / ((s->lds_bytes + HG_LDS_GRANULE - 1) / HG_LDS_GRANULE * HG_LDS_GRANULE);
+        if (by_lds >= 1 && by_lds < s->waves_per_cu) s->waves_per_cu = by_lds;
+    }
+    if (const char *w = getenv("HG_WAVES_PER_CU")) {      // diagnostics: fewer resident waves per CU, by asking for more LDS per wave
+        const int k = atoi(w);
+        if (k >= 1 && k < s->waves_per_cu && HG_LDS_PER_CU / k >= s->lds_bytes) {
+            s->waves_per_cu = k;
+            s->lds_bytes = HG_LDS_PER_CU / k / HG_LDS_GRANULE * HG_LDS_GRANULE;
+        }
+    }
+
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_stride);
     if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(float) * (size_t)n_envs * s->state_stride);
@@ -636,8 +653,10 @@ int hg_step(hg_sim *s, const float *actions_dev, const int32_t *joint_sel, int n
         // (hex) every env with that byte as the per-slot priority pattern (default 0xE4).
         static const char *ov = getenv("HG_PRIO_FLIP");
         static const long ovv = ov ? strtol(ov, nullptr, 16) : -1;
-        const long resident = (long)s->n_cu * 4 * hg::kVariants[s->variant].wpe;
+        const long resident = (long)s->n_cu * s->waves_per_cu;
         P.flip_from = (!ov && (long)s->n_envs > resident) ? (int)(s->n_envs - resident / 2) : 0;
+        static const char *ff = getenv("HG_FLIP_FROM");      // diagnostics (tools/prio_ab.sh)
+        if (ff) P.flip_from = atoi(ff);
         if (!ov || ovv != 0) P.flags |= F_PRIOFLIP | (int)(((ovv > 1 ? ovv : 0xE4) & 0xff) << 8);
     }
     P.dt = (float)c.dt; P.inv_dt = (float)(1.0 / c.dt);

@@ -886,9 +886,24 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
         for (int k = 0; k < NC3; k++) BC[k] = 0.f;
         float diagB = 0.f;
+        unsigned long long ovmask = 0ull;      // links on the path(s) of the overflow rows' contact (wave-uniform), and the deeper path's depth
+        int ovlev = 0;
+        if constexpr (NOV > 0) {
+            const unsigned long long m = R1.myanc | R1.myanc2;
+            const int p1 = __popcll(R1.myanc), p2 = __popcll(R1.myanc2);
+            ovlev = __builtin_amdgcn_readfirstlane(p1 > p2 ? p1 : p2);
+            ovmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m) |
+                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)) << 32);
+        }
         auto response = [&](auto PO_, const RowVars &R, VA0 &XM0, VA1 &XM1, VA2 &XM2, VA3 &XM3, float (&XC)[NC3 > 0 ? NC3 : 1], float &xdiag)
                             __attribute__((always_inline)) {
             constexpr bool PATHONLY = decltype(PO_)::value != 0;      // contact rows of row set 1: links on the contact paths only, no motor columns
+            // overflow rows (the friction pair of ONE contact): only their mutual entries are wanted, so only the links of that
+            // contact's own path(s) are descended and only the overflow columns accumulated
+            constexpr bool OVP = PATHONLY && NOV > 0;
+            constexpr int C0 = OVP ? NCL : 0;
+            const unsigned long long dmask = OVP ? ovmask : rowmask;
+            const int wlev = OVP ? ovlev : maxlev;
             const int col = R.col, body = R.body;
             const bool unit_row = R.motor || R.slot;
             const unsigned pw[3] = {R.pw[0], R.pw[1], R.pw[2]};
@@ -899,7 +914,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
             for (int dd = DEPTH; dd >= 1; --dd) {
                 float Y = 0.f;
-                if (dd <= maxlev) {      // wave-uniform
+                if (dd <= wlev) {        // wave-uniform
                     const int l = (int)((pw[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                     if (l >= 0) {
                         const float *pc = cacheL + CACHE * l;
@@ -921,7 +936,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int dd = DEPTH; dd >= 1; --dd) {
                     float Y = 0.f;
-                    if (dd <= maxlev) {
+                    if (dd <= wlev) {
                         const int l = (int)((R.pw2[(dd - 1) >> 2] >> (8 * ((dd - 1) & 3))) & 0xffu) - 1;
                         if (l >= 0) {
                             const float *pc = cacheL + CACHE * l;
@@ -947,7 +962,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
                 for (int k = 0; k < 6; k++)
 #pragma unroll
-                    for (int c = 0; c < NC3; c++) XC[c] = fmaf(ub[k], JcL[k * NC3 + c], XC[c]);
+                    for (int c = C0; c < NC3; c++) XC[c] = fmaf(ub[k], JcL[k * NC3 + c], XC[c]);
             }
             // (iii) full descent: joint accelerations of every link for this row's impulse.  Unrolled over the links: the link
             // index is a compile-time constant (the motor column is a named register, the cache record a constant LDS
@@ -966,7 +981,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             }
 #pragma unroll
             for (int i = 0; i < NMX; ++i) {      // (a plain loop, fully unrolled: a closure per link sent the slots to scratch)
-                if (i < n && (!PATHONLY || ((rowmask >> i) & 1ull))) {
+                if (i < n && (!PATHONLY || ((dmask >> i) & 1ull))) {
                 const unsigned inf = (unsigned)__builtin_amdgcn_readlane((int)info_w, i);
                 const int mode = (int)(inf & 0x3u);
                 const float *pc = cacheL + CACHE * i;
@@ -1012,7 +1027,10 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if (unit_row && i == body) xdiag = R.unit_f * qa;
                 if (nc > 0 && ((rowmask >> i) & 1ull)) {      // wave-uniform: rows of Jc off every contact path are zero
                     const float *jr = JcL + (6 + i) * NC3;
-                    if constexpr (NC3 % 4 == 0) {
+                    if constexpr (OVP) {
+#pragma unroll
+                        for (int c = C0; c < NC3; c++) XC[c] = fmaf(qa, jr[c], XC[c]);
+                    } else if constexpr (NC3 % 4 == 0) {
 #pragma unroll
                         for (int c = 0; c < NC3; c += 4) {
                             const float4 j4 = *reinterpret_cast<const float4 *>(jr + c);
@@ -1391,7 +1409,20 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         };
         auto overflow_pair = [&](const int k, const float lim) {      // overflow rows k, k + 1: the friction pair of one contact
             const float lt = fmaf(lim_s, lam_l, lamv0);               // joint impulse on motor lanes, the row's own elsewhere
-            const float S0 = wave_sum(AOr[k] * lt), S1 = wave_sum(AOr[k + 1] * lt);
+            // both sums in one reduction: v_permlane32_swap puts the partial products of row k on lanes 0-31 and those of
+            // row k + 1 on lanes 32-63, each half is then summed on its own
+            float S0, S1;
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(AOr[k] * lt), __float_as_uint(AOr[k + 1] * lt), false, false);
+                float x = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));      // row_ror:2
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));      // row_ror:1
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1, 3
+                S0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 31));
+                S1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+            }
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 float acc = ov_b[k + r] - (r ? S1 : S0);
@@ -1403,30 +1434,34 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 z = fmaf(AC[NCL + k + r], d, z);
             }
         };
+        auto friction_pair = [&](const int c, const float lim) __attribute__((always_inline)) {      // compile-time c
+            if (MAXC + 2 * c + 1 < NCL) {
+                lane_row_update_sym(NMX + MAXC + 2 * c, AC[MAXC + 2 * c < NCL ? MAXC + 2 * c : 0], lim);
+                lane_row_update_sym(NMX + MAXC + 2 * c + 1, AC[MAXC + 2 * c + 1 < NCL ? MAXC + 2 * c + 1 : 0], lim);
+            } else {
+                overflow_pair(MAXC + 2 * c >= NCL ? MAXC + 2 * c - NCL : 0, lim);
+            }
+        };
         auto contact_rows = [&]() {
-            if (nc > 0) {
-                if (nc == MAXC) {       // every slot taken (a robot standing on two feet): the normals as one run, no tests
-                    row_run(NMX, MAXC, true, [&](const int c) -> float { return AC[c >= 0 && c < MAXC ? c : 0]; });
-                } else {
+            if (nc == MAXC) {
+                // every slot taken (a robot standing on two feet): the normals as one run, no slot tests.  (The test of the
+                // normal impulse stays: a friction pair under a normal impulse of 0 KEEPS its impulse, as in Bullet's sweep.)
+                row_run(NMX, MAXC, true, [&](const int c) -> float { return AC[c >= 0 && c < MAXC ? c : 0]; });
 #pragma unroll
-                    for (int c = 0; c < MAXC; ++c)
-                        if (c < nc) lane_row_update(NMX + c, AC[c], lo, hi);
+                for (int c = 0; c < MAXC; ++c) {
+                    const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lamv0), NMX + c);
+                    if (tot_i > 0) friction_pair(c, mu_v * __int_as_float(tot_i));
                 }
+            } else if (nc > 0) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < nc) lane_row_update(NMX + c, AC[c], lo, hi);
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c)
                     if (c < nc) {
                         const int tot_i = __builtin_amdgcn_readlane(__float_as_int(lamv0), NMX + c);
-                        if (tot_i > 0) {                      // tot > 0 on the scalar unit (positive float bits)
-                            const float lim = mu_v * __int_as_float(tot_i);
-                            if constexpr (true) {
-                                if (MAXC + 2 * c + 1 < NCL) {
-                                    lane_row_update_sym(NMX + MAXC + 2 * c, AC[MAXC + 2 * c < NCL ? MAXC + 2 * c : 0], lim);
-                                    lane_row_update_sym(NMX + MAXC + 2 * c + 1, AC[MAXC + 2 * c + 1 < NCL ? MAXC + 2 * c + 1 : 0], lim);
-                                } else {
-                                    overflow_pair(MAXC + 2 * c >= NCL ? MAXC + 2 * c - NCL : 0, lim);
-                                }
-                            }
-                        }
+                        if (tot_i > 0)                        // tot > 0 on the scalar unit (positive float bits)
+                            friction_pair(c, mu_v * __int_as_float(tot_i));
                     }
             }
         };
