@@ -18,6 +18,7 @@
 namespace hg {
 
 constexpr int WAVE  = 64;
+#define HG_XCDS 8           // accelerator complex dies of an MI355X: workgroups are dealt to them round-robin
 constexpr int DMAX  = 12;   // deepest supported link (base children are depth 1)
 constexpr int NSLOT = 2;    // saved-acceleration slots = deepest nesting of branching links (slots are recycled)
 constexpr int LINKC = 32;   // floats per link in DevModel::link

@@ -140,7 +140,16 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     static_assert((6 * NC3) % 4 == 0, "the joint part of Jc must start on a 16-byte boundary (even MAXC)");
 
     extern __shared__ __align__(16) float lds[];
-    const int env = blockIdx.x;
+    // XCD-aware env order.  Workgroups go to the 8 XCDs round-robin (workgroup b -> XCD b % 8), each XCD with its own L2:
+    // with env = b the rows of the small per-env arrays (actions, running statistics, observations, flags: 4 ... 112
+    // bytes) of eight consecutive envs would share 128-byte lines fetched by eight different L2s.  XCD x takes a
+    // contiguous block of envs instead: q = n / 8 each, the first n % 8 XCDs one more.
+    const int disp = blockIdx.x;           // dispatch order (the wave-priority schedule below goes by it)
+    int env;
+    {
+        const int x = disp & (HG_XCDS - 1), q = P.n_envs / HG_XCDS, r = P.n_envs % HG_XCDS;
+        env = x * q + (x < r ? x : r) + disp / HG_XCDS;
+    }
     const int lane_o = threadIdx.x;
     const int n_o = P.n;
     const int lane = lane_o, n = n_o;
@@ -1114,7 +1123,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         // apart (tree sweeps of one wave under the solver of another).  Measured with tools/phase_ticks.py.
         // Launches of several resident rounds mix their phases by themselves and lose 2 % to the flip, but their tail has the
         // same problem: the host sets flip_from to 0 for launches that fit the GPU at once and to the last half round otherwise.
-        if ((P.flags & F_PRIOFLIP) && env >= P.flip_from) {
+        if ((P.flags & F_PRIOFLIP) && disp >= P.flip_from) {
             const int wslot = __builtin_amdgcn_s_getreg(6148) & 3;      // HW_ID.wave_id[1:0]: slot of this wave on its SIMD
             // priority of slot w: bits [2w, 2w + 2) of the pattern byte in flags (0xE4 = 0, 1, 2, 3); odd substeps mirror it
             set_prio((int)((unsigned)P.flags >> (8 + 2 * ((sub & 1) ? 3 - wslot : wslot))));      // the next substep's tree phases keep this order, its solver flips it back

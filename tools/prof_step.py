@@ -20,6 +20,8 @@ replay = bool(rest and rest[0] == "replay")
 if rand or replay:
     rest.pop(0)
 model, cfg = load_robot(robot)
+if replay:
+    cfg.store_torques = False      # as bench.py / NaoEnv: nothing on that path reads the motor torques
 for kv in rest:
     k, v = kv.split("=")
     setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
