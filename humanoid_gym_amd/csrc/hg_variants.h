@@ -12,7 +12,7 @@ struct Variant { int nmx, maxc, depth, nsl, wpe; };
     X(0, 18, 12, 6, 0, 4)  /* dancer (scratch-free at 4 waves/SIMD since round 2; 3 waves/SIMD is 18 % slower) */ \
     X(1, 26, 8, 6, 0, 4)   /* nao with the default 8 contact slots     */ \
     X(2, 28, 8, 6, 0, 4)   /* up to 28 dofs, shallow tree              */ \
-    X(3, 28, 12, 6, 0, 4)  /* nao, 12 contact slots                    */ \
+    X(3, 28, 12, 6, 0, 3)  /* nao, 12 contact slots (64 rows: 632 B of scratch per lane at 4 waves/SIMD) */ \
     X(4, 20, 8, 9, 2, 4)   /* pepper (deep chain, branching torso)     */ \
     X(5, 20, 8, 12, 2, 4)  /* 20 dofs, deeper chains                   */ \
     X(6, 28, 12, 12, 2, 3) /* deep trees up to 28 dofs, 12 contacts    */ \
