@@ -232,6 +232,9 @@ static void kinematics(const hg_model *m, const double *st, scratch_t *w) {
 /* articulated-body algorithm: unconstrained accelerations             */
 /* acc = [base angular (world), base linear (world, of the COM), qdd]  */
 /* ------------------------------------------------------------------ */
+static double hgo_noise_eps;            /* the noise probe of the tests, defined with hgo_set_row_noise below */
+static double noise_factor(void);
+
 static int aba(const hg_model *m, const hg_config *c, const double *st, const double *tau,
                scratch_t *w, double *acc) {
     const int n = m->n_links;
@@ -271,11 +274,17 @@ static int aba(const hg_model *m, const hg_config *c, const double *st, const do
             pA[b][k] += Iw[k] * (c->ang_damping + c->ang_damping * wn);
             pA[b][3 + k] = mass * t[k] - mass * g[k] + mass * v[b][3 + k] * (c->lin_damping + c->lin_damping * vn);
         }
+        if (hgo_noise_eps > 0)      /* noise probe: the velocity-product terms as a float32 recursion over the chain leaves them */
+            for (int k = 0; k < 6; k++) { if (b > 0) cor[i][k] *= noise_factor(); pA[b][k] *= noise_factor(); }
     }
     for (int i = n - 1; i >= 0; i--) {
         const int b = i + 1, p = m->parent[i] + 1;
         double D = 0, Ia[36], pa[6], X[36], T[36];
         HGO_FLOPS(72 + 12 + 1 + 14 + 108 + 90 + 432 + 468 + 6);   /* U, D, 1/D, u, Ia, pa, Ia X, X^T (Ia X) +=, pA += */
+        if (hgo_noise_eps > 0)      /* noise probe: the accumulated articulated inertia as float32 sums leave it (the rank-one
+                                       downdate below cancels: a light link under a heavy subtree amplifies this) */
+            for (int r = 0; r < 6; r++)
+                for (int k = r; k < 6; k++) { IA[b][6 * r + k] *= noise_factor(); IA[b][6 * k + r] = IA[b][6 * r + k]; }
         for (int r = 0; r < 6; r++) {
             double s = 0;
             for (int k = 0; k < 6; k++) s += IA[b][6 * r + k] * w->S[i][k];
@@ -409,7 +418,11 @@ static void plane_space(const double n[3], double p[3], double q[3]) {
  * M^-1 J^T, its right-hand side and its diagonal by an independent relative error of standard deviation eps -- which is
  * what the roundings of a float32 ABA / Jacobian chain leave in those numbers (eps ~ 1e-6 = 16 ulp) -- and every
  * collision sphere's world centre is moved by eps * 0.3 m per coordinate (3e-7 m: float32 positions of O(1 m) after a
- * chain of transforms), which reaches contact points, normals, distances and through them the tangent basis.  The noise stream
+ * chain of transforms), which reaches contact points, normals, distances and through them the tangent basis.  The same
+ * relative error goes into the articulated-body pass itself: every link's velocity-product acceleration and bias force,
+ * and its accumulated articulated inertia before the rank-one downdate -- that downdate cancels, so a light link under a
+ * heavy subtree (mass ratios of 1000 in the fuzzers' trees) amplifies float32 rounding a thousandfold, which noise on the
+ * finished rows alone does not show (tools/fuzz_fail/r3final_tree411).  The noise stream
  * of env e is seeded with (seed, e), so a batch of identical envs samples the spread of the answer. */
 static double hgo_noise_eps = 0.0;
 static uint64_t hgo_noise_seed = 0;

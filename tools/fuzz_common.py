@@ -70,7 +70,8 @@ def _ulp_nudge(x64, rng):
     return np.where(b32 != 0, moved, b32)
 
 
-def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None, n_envs=None, n_steps=None):
+def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None, n_envs=None, n_steps=None,
+             min_allowed=1):
     """Steps one case; raises AssertionError (after printing what it knows) on a failure."""
     n = model.n_links
     N_ENVS = n_envs or globals()["N_ENVS"]
@@ -87,7 +88,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     # q [rad]; qd [rad/s] (q error = dt * qd error); motor torque relative to max(1, largest torque).  A contact force is
     # m erp depth / dt^2: the 1e-7 m that chained FP32 transforms leave in a sphere centre are 0.1 N on a 28 kg Pepper at
     # dt = 1/480, 2 % of its hip torque with the angles equal to 1e-7 rad -- the torque tolerance follows 1 / dt^2
-    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2))
+    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed)
     lim_idx = np.flatnonzero(model.limited)
     vlim = 0.9 * (min(cfg.max_coord_velocity, 100.0) if cfg.max_coord_velocity > 0 else 100.0)
     fast = lambda st: (np.abs(st[:, 7:13]).max(1) > vlim) | (np.abs(st[:, 13 + n:13 + 2 * n]).max(1) > vlim)
@@ -110,7 +111,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
             dump = os.path.join(dump, sub_dir)
             os.makedirs(dump, exist_ok=True)
             np.savez(os.path.join(dump, "sample.npz"), before=before, act=act, sel=np.asarray([] if sel is None else sel, np.int32), sub=sub, env=e,
-                     kernel_q=gq, oracle_q=o["q"], max_force=model.max_force, max_vel=model.max_vel,
+                     kernel_q=gq, oracle_q=o["q"], max_force=model.max_force, max_vel=model.max_vel, mass=model.mass, inertia=model.inertia,
                      base_cmd=np.zeros((0, 3)) if base_cmd is None else base_cmd)
             json.dump(dict(tag=tag, cfg=dataclasses.asdict(cfg), has_sel=sel is not None, urdf=urdf is not None, name=model.name), open(os.path.join(dump, "sample.json"), "w"))
             if urdf:

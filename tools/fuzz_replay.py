@@ -21,6 +21,8 @@ else:
     model.lower, model.upper = model.lower.astype(np.float32).astype(np.float64), model.upper.astype(np.float32).astype(np.float64)
 if "max_force" in z.files:
     model.max_force, model.max_vel = z["max_force"], z["max_vel"]
+if "mass" in z.files:          # fuzz_trees.py scales the link masses of some shapes
+    model.mass, model.inertia = z["mass"], z["inertia"]
 base_cmd = z["base_cmd"] if "base_cmd" in z.files and len(z["base_cmd"]) else None
 n = model.n_links
 print(meta["tag"], "env", e)

@@ -36,14 +36,17 @@ def run(n_cases=60, seed=1):
             model = load_urdf(path, base_position=(0, 0, float(rng.uniform(0.05, 0.3))), self_collision=self_on, name="tree")
         except Exception as e:          # the generator cannot build this shape (e.g. too shallow for the link count)
             print(tag, "-> generator:", str(e)[:80]); refused += 1; continue
-        if rng.random() < 0.3:          # mass ratios of up to 1000 between neighbouring links (the generator draws 0.05 .. 0.4 kg)
+        scaled = rng.random() < 0.3
+        if scaled:                      # mass ratios of up to 1000 between neighbouring links (the generator draws 0.05 .. 0.4 kg)
             k = 10.0 ** rng.uniform(-2, 1, model.n_links)
             model.mass, model.inertia = model.mass * k, model.inertia * k[:, None]
         cfg = SimConfig()
         for k, v in over.items():
             setattr(cfg, k, v)
         try:
-            run_case(tot, tag, model, cfg, sub, rng, -1.0, 1.0, model.n_act, tol=2e-4, base_vel=0.5, urdf=path)
+            # a light link under a heavy subtree: the articulated inertia's rank-one downdate cancels and float32 loses three
+            # digits there; such samples must still be EXPLAINED by the oracle's spread, but up to 3 per case may occur
+            run_case(tot, tag, model, cfg, sub, rng, -1.0, 1.0, model.n_act, tol=2e-4, base_vel=0.5, urdf=path, min_allowed=3 if scaled else 1)
         except HgError as e:
             print(tag, "-> refused:", str(e)[:100]); refused += 1; continue
         dual += int(model.n_links + 3 * cfg.max_contacts > 64); sizes.append(model.n_links)
