@@ -289,3 +289,11 @@ def test_hg_create_rejects_numbers_the_step_cannot_use():
     assert b"config" in rejected(edit_cfg=lambda cc: setattr(cc, "kp", -0.1))
     if len(m.pair_a):
         assert b"within one body" in rejected(lambda cm: cm.pair_b.__setitem__(0, cm.pair_a[0]))
+    # a ground primitive is a point or a sphere: segments take part in link-link pairs only
+    ground = next(k for k in range(len(m.sphere_link)) if m.sphere_flags[k] & 1)
+    assert b"point or a sphere" in rejected(put("sphere_half", ground, 0.01, 2))
+    # Bullet's residual early-out lives in the oracle only (measured never to trigger: DESIGN 1); the library says so
+    # instead of ignoring the field
+    cm, cc = m.to_c(), cfg.to_c()
+    cc.residual_threshold = 1e-7
+    assert L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h)) == -4 and b"residual_threshold" in L.hg_last_error()
