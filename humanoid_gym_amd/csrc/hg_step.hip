@@ -15,7 +15,8 @@
 //     level, parent <-> child data goes through LDS;
 //   * the leaves -> root ABA pass: 7 lanes per link, one per column of X^T Ia X plus one for the
 //     bias force;
-//   * contact detection: lanes stride over the collision spheres;
+//   * contact detection: trips of 64 collision primitives, lane = primitive (hull points against the plane ranked per body in
+//     a 64-float LDS window; pairs of sphere-swept segments between links);
 //   * constraint rows: lane r owns row r (motor rows first, then contact
 //     normals, then friction pairs).  Each lane computes M^-1 J_r^T with its own
 //     walk over the tree (path to the root, then a full descent reading the
@@ -27,9 +28,12 @@
 //     with A[j][i].  This is the impulse-space form of Bullet's velocity-space
 //     sweep (w = J dv), same iterates, no reductions; violated joint limits ride
 //     along as extra rows on the wave's spare lanes.  Models with more than 64 rows (NAO / Romeo with
-//     their finger joints) carry two rows per lane -- motor row and contact row -- with the impulses in
-//     two VGPRs and the CHANGE of an impulse broadcast instead (see "row layout" in phase 4);
+//     their finger joints): 65-66 rows keep one row per lane and run the friction pair of the last contact slot as
+//     "overflow rows" from a wave reduction per sweep; beyond that every lane carries two rows -- motor row and contact
+//     row.  Either way the impulses live on their lanes and the CHANGE of an impulse is broadcast (see "row layout"
+//     in phase 4), the sweeps written as blocks of issue slots in assembly;
 //   * the final M^-1 J^T lambda is one more level-by-level ABA response.
+// Env order: XCD-aware (workgroup b runs on XCD b % 8; each XCD steps a contiguous block of envs).
 // Scheduling: one wave per workgroup (a workgroup of several envs keeps its LDS until its slowest wave ends:
 // measured slower); launches that fit the GPU at once reverse the SIMD arbiter's service order of their
 // waves at solver entry with s_setprio (see 4b), so that the waves of a SIMD finish together.
