@@ -12,7 +12,7 @@
 
 #ifdef HG_PHASE_TIMING      // diagnostics build (tools/phase_ticks.py)
 #define HG_TICK_ENVS 4096
-#define HG_TICK_SLOTS 16
+#define HG_TICK_SLOTS 24
 #endif
 
 namespace hg {

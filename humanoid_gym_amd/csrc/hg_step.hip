@@ -964,6 +964,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 }
                 Z = Z + Z2;
             }
+            HG_TICK(16);      // (the last call's stamps stay: the rows that have a lane)
             // (ii) base
             Z.a = Z.a - R.Jang;
             Z.l = Z.l - R.Jlin;
@@ -984,6 +985,11 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
             // of a saved branching link -- picked with selects under scalar conditions inside ONE uniform branch, so that a
             // chain link (the common case) pays nothing and nothing is copied at a merge point.
             static_assert(NSL <= 2, "two saved-acceleration slots");
+            HG_TICK(17);
+            // (Reading a link's cache record one link AHEAD was tried: every link is its own basic block, so hipcc does not
+            // hoist the four LDS reads and a lone wave waits for them once per link.  LDS returns in order, so the reads of the
+            // contact Jacobian rows behind the prefetch wait for it anyway; 16 more live VGPRs spill the 4-waves-per-SIMD
+            // shapes; the 42-dof descent got 20 % slower.  Not kept.)
             Sv a = ab, slot0 = ab, slot1 = ab;
             // own-path Y values by depth in one register vector, read with the link's depth as index
             typedef float V16f __attribute__((ext_vector_type(16)));

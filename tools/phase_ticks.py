@@ -65,8 +65,8 @@ for t in range(60, 100):
 e1.record(); torch.cuda.synchronize()
 print(f"{robot} {n_envs} envs {overrides}: {e0.elapsed_time(e1) / 40:.4f} ms per step (diagnostics build), variant {os.environ.get('HG_VARIANT', 'auto')}")
 ne = min(n_envs, 4096)
-buf = np.zeros((ne, 16), np.uint64)
-assert L.hg_debug_phase_ticks(buf.ctypes.data_as(C.c_void_p), ne) == 16
+buf = np.zeros((ne, 24), np.uint64)
+assert L.hg_debug_phase_ticks(buf.ctypes.data_as(C.c_void_p), ne) == 24
 tk = buf[:, :13].astype(np.int64)
 d = np.diff(tk, axis=1)                       # [env, 12] clocks per phase
 total = tk[:, 12] - tk[:, 0]
@@ -101,6 +101,11 @@ for k in np.unique(wid):
 if buf[:, 15].any():
     ov = (buf[:, 15].astype(np.int64) - tk[:, 7]) * kc
     print(f"  of the impulse responses: overflow rows' path-only response {ov.mean():.2f}k (min {ov.min():.2f}k, max {ov.max():.2f}k)")
+if buf[:, 16].any():
+    t16, t17 = buf[:, 16].astype(np.int64), buf[:, 17].astype(np.int64)
+    first = np.where(buf[:, 15] != 0, buf[:, 15].astype(np.int64), tk[:, 7])
+    print(f"  of the response of the rows that have a lane: own-path walk {(t16 - first).mean() * kc:.2f}k, base {(t17 - t16).mean() * kc:.2f}k, "
+          f"descent over the links {(tk[:, 8] - t17).mean() * kc:.2f}k")
 print(f"{'phase':58s} {'mean kclk':>9s} {'min':>7s} {'max':>7s} {'share':>6s}")
 for k, name in enumerate(PHASES):
     c = d[:, k] * kc
