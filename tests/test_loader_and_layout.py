@@ -266,6 +266,58 @@ def test_welded_child_after_revolute_sibling_keeps_a_bodys_spheres_contiguous(tm
         L.hg_destroy(h)
 
 
+def test_a_body_welded_from_many_boxes_keeps_at_most_64_primitives(tmp_path):
+    """One body's primitives share one 64-lane trip of the kernel's contact detection (hg_create refuses more).  A carrier
+    with nine welded boxes would have 80 hull points + 10 capsules: the loader keeps the hull support points of the UNION
+    (what a plane can touch of the whole body), every capsule, and hg_create accepts the model."""
+    import ctypes as C
+    from humanoid_gym_amd import _capi
+    from humanoid_gym_amd.model import SimConfig
+    from humanoid_gym_amd.urdf import load_urdf, BODY_MAX_PRIMITIVES
+
+    def link(name, box):
+        return (f'<link name="{name}"><inertial><mass value="0.2"/><inertia ixx="1e-3" ixy="0" ixz="0" iyy="1e-3" iyz="0" izz="1e-3"/>'
+                f'</inertial><collision><geometry><box size="{box}"/></geometry></collision></link>')
+
+    parts = [link("base", "0.1 0.1 0.1"), link("arm", "0.02 0.02 0.2")]
+    joints = ['<joint name="j" type="revolute"><parent link="base"/><child link="arm"/><origin xyz="0 0 0.2"/><axis xyz="0 1 0"/>'
+              '<limit lower="-1" upper="1" effort="5" velocity="5"/></joint>']
+    for k in range(9):
+        parts.append(link(f"plate{k}", "0.05 0.03 0.02"))
+        joints.append(f'<joint name="w{k}" type="fixed"><parent link="base"/><child link="plate{k}"/>'
+                      f'<origin xyz="{0.08 * math.cos(k)} {0.08 * math.sin(k)} {0.02 * k - 0.08}" rpy="0 0 {0.7 * k}"/></joint>')
+    path = tmp_path / "plates.urdf"
+    path.write_text('<robot name="plates">' + "".join(parts + joints) + "</robot>")
+    m = load_urdf(str(path), self_collision=True, name="plates")
+    on_base = [k for k in range(len(m.sphere_link)) if m.sphere_link[k] == -1]
+    assert len(on_base) <= BODY_MAX_PRIMITIVES
+    assert sum(1 for k in on_base if m.sphere_flags[k] & 2) == 10                       # every capsule kept
+    pts = np.array([m.sphere_pos[k] for k in on_base if m.sphere_flags[k] & 1])
+    assert 26 <= len(pts) <= BODY_MAX_PRIMITIVES - 10
+    L = _capi.load_library()
+    h = C.c_void_p()
+    cm, cc = m.to_c(), SimConfig(enable_self=True).to_c()
+    rc = L.hg_create(C.byref(cm), C.byref(cc), 2, 0, C.byref(h))
+    assert rc in (0, -2), (rc, L.hg_last_error())
+    if rc == 0:
+        L.hg_destroy(h)
+    # and the check it protects from: 65 primitives on one body are refused with a message, not run
+    extra = BODY_MAX_PRIMITIVES + 1 - len(on_base)
+    first = on_base[0]
+    crowded = load_urdf(str(path), self_collision=True, name="plates")      # ... with copies of a base point appended to the base's run
+    k_end = max(on_base) + 1
+    for name in ("sphere_link", "sphere_flags", "sphere_radius"):
+        arr = np.asarray(getattr(crowded, name))
+        setattr(crowded, name, np.concatenate([arr[:k_end], np.repeat(arr[first:first + 1], extra, 0), arr[k_end:]]))
+    for name in ("sphere_pos", "sphere_half"):
+        arr = np.asarray(getattr(crowded, name))
+        setattr(crowded, name, np.concatenate([arr[:k_end], np.repeat(arr[first:first + 1], extra, 0), arr[k_end:]]))
+    crowded.pair_a = np.where(np.asarray(crowded.pair_a) >= k_end, np.asarray(crowded.pair_a) + extra, crowded.pair_a)
+    crowded.pair_b = np.where(np.asarray(crowded.pair_b) >= k_end, np.asarray(crowded.pair_b) + extra, crowded.pair_b)
+    rc = L.hg_create(C.byref(crowded.to_c()), C.byref(cc), 2, 0, C.byref(h))
+    assert rc == -4 and b"more than 64 collision primitives on one body" in L.hg_last_error(), (rc, L.hg_last_error())
+
+
 def test_hands_variants_of_nao_and_romeo():
     """romeo_env.py:24-26 filters Finger / Thumb joints out of the CONTROLLED set: they are simulated dofs of the
     reference's robots.  hands=True / "<robot>_hands" load the stand-ins that have them; the env-facing joint lists
