@@ -1417,15 +1417,6 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 lane_row_update(b + j, col(j), lo, hi);
             }
         };
-        auto wave_sum = [&](float x) -> float {      // sum over the 64 lanes, wave-uniform result
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));      // row_ror:2
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));      // row_ror:1: every lane holds its row's sum
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1, 3
-            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2, 3
-            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
-        };
         auto overflow_pair = [&](const int k, const float lim) {      // overflow rows k, k + 1: the friction pair of one contact
             const float lt = fmaf(lim_s, lam_l, lamv0);               // joint impulse on motor lanes, the row's own elsewhere
             // both sums in one reduction: v_permlane32_swap puts the partial products of row k on lanes 0-31 and those of
