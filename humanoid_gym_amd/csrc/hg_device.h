@@ -24,8 +24,9 @@ constexpr int NSLOT = 2;    // saved-acceleration slots = deepest nesting of bra
 constexpr int LINKC = 32;   // floats per link in DevModel::link
 // floats per link in the LDS articulated-body cache: 22 used, records 16-byte aligned.  28 (stride of 8 distinct LDS
 // banks for the lane = link accesses) unless the model is so large that LDS bounds the occupancy: 24 lets a Romeo with
-// hands (61 links) run 8 instead of 6 waves per CU (+10 %); on Pepper 24 is 1.4 % slower than 28, on NAO 0.7 % faster.
-__host__ __device__ constexpr int cache_stride(int nmx) { return nmx > 48 ? 24 : 28; }
+// hands (61 links) run 8 instead of 6 waves per CU (+10 %) and a NAO with fingers (42 links) 12 instead of 11 -- what its
+// registers admit (+4 %); on Pepper 24 is 1.4 % slower than 28, on the 26-dof NAO 0.7 % faster.
+__host__ __device__ constexpr int cache_stride(int nmx) { return nmx > 40 ? 24 : 28; }
 constexpr int PUB   = 20;   // floats per body in the LDS kinematics exchange
 constexpr int UP    = 28;   // floats per link in the LDS child->parent exchange
 constexpr int CON   = 12;   // floats per contact record
