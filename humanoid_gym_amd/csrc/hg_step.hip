@@ -899,6 +899,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
 #pragma unroll
         for (int k = 0; k < NC3; k++) BC[k] = 0.f;
         float diagB = 0.f;
+        // One row per lane + overflow rows (the 42-dof NAO): lane i keeps the cache record of ITS link -- r_w, 1/D, U, S, 16 floats
+        // -- in VGPRs through the response passes, and the descent fetches link i's record with 16 v_readlane into SGPRs
+        // instead of four broadcast LDS reads: every use of the record is scalar x vector, which is what an SGPR operand is for,
+        // and the LDS reads of the contact Jacobian rows no longer queue behind them.  Same-box A/B (tools/recreg_ab.sh): the
+        // bench workload (8 contacts: two descents per step) +3.9 %, the same robot under random targets (4 contacts) -1.1 %;
+        // Romeo's 37-dof shape -4 % and the two-rows-per-lane shape -0.5 % (registers), so they keep the LDS reads.
+#ifndef HG_RECREG
+#define HG_RECREG 1        // 0: the LDS reads everywhere (A/B builds, tools/recreg_ab.sh)
+#endif
+        constexpr bool RECREG = HG_RECREG && NOV > 0;
+        float4 rq0 = {0.f, 0.f, 0.f, 0.f}, rq1 = rq0, rq2 = rq0, rq3 = rq0;
+        if constexpr (RECREG) {
+            static_assert(C_RW == 0 && C_DINV == 3 && C_UW == 4 && C_SW == 10, "cache record layout");
+            const float *pc = cacheL + CACHE * (lane < n ? lane : 0);
+            rq0 = *reinterpret_cast<const float4 *>(pc); rq1 = *reinterpret_cast<const float4 *>(pc + 4);
+            rq2 = *reinterpret_cast<const float4 *>(pc + 8); rq3 = *reinterpret_cast<const float4 *>(pc + 12);
+        }
         unsigned long long ovmask = 0ull;      // links on the path(s) of the overflow rows' contact (wave-uniform), and the deeper path's depth
         int ovlev = 0;
         if constexpr (NOV > 0) {
@@ -1010,9 +1027,16 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                     a.a.z = m3 ? slot1.a.z : (m2 ? slot0.a.z : ab.a.z); a.l.x = m3 ? slot1.l.x : (m2 ? slot0.l.x : ab.l.x);
                     a.l.y = m3 ? slot1.l.y : (m2 ? slot0.l.y : ab.l.y); a.l.z = m3 ? slot1.l.z : (m2 ? slot0.l.z : ab.l.z);
                 }
-                // the cache record [0:16): r_w, 1/D, U, S as four 16-byte LDS reads
-                const float4 c0 = *reinterpret_cast<const float4 *>(pc), c1 = *reinterpret_cast<const float4 *>(pc + 4),
-                             c2 = *reinterpret_cast<const float4 *>(pc + 8), c3 = *reinterpret_cast<const float4 *>(pc + 12);
+                // the cache record [0:16): r_w, 1/D, U, S -- 16 readlanes of lane i's copy, or four 16-byte LDS reads
+                float4 c0, c1, c2, c3;
+                if constexpr (RECREG) {
+                    auto rl = [&](const float v) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); };
+                    c0 = {rl(rq0.x), rl(rq0.y), rl(rq0.z), rl(rq0.w)}; c1 = {rl(rq1.x), rl(rq1.y), rl(rq1.z), rl(rq1.w)};
+                    c2 = {rl(rq2.x), rl(rq2.y), rl(rq2.z), rl(rq2.w)}; c3 = {rl(rq3.x), rl(rq3.y), rl(rq3.z), rl(rq3.w)};
+                } else {
+                    c0 = *reinterpret_cast<const float4 *>(pc); c1 = *reinterpret_cast<const float4 *>(pc + 4);
+                    c2 = *reinterpret_cast<const float4 *>(pc + 8); c3 = *reinterpret_cast<const float4 *>(pc + 12);
+                }
                 static_assert(C_RW == 0 && C_DINV == 3 && C_UW == 4 && C_SW == 10, "cache record layout");
                 a.l = a.l + cross(a.a, v3(c0.x, c0.y, c0.z));        // the same acceleration at this link's origin
                 // Y of this link: non-zero only if it is the own-path link of its depth d (wave-uniform)
