@@ -9,7 +9,7 @@ from humanoid_gym_amd._capi import HgSim
 from humanoid_gym_amd.workloads import random_actions
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-for name, n_envs, sub, kw in (("nao", 4096, 1, {}), ("pepper", 4096, 1, {}), ("romeo", 2048, 1, {"enable_self": True}),
+for name, n_envs, sub, kw in (("nao_hands", 4096, 1, {}), ("romeo_hands", 2048, 1, {}), ("nao", 4096, 1, {}), ("pepper", 4096, 1, {}), ("romeo", 2048, 1, {"enable_self": True}),
                               ("dancer", 4096, 4, {}), ("dancer", 2048, 4, {"enable_self": True})):
     model, cfg = load_robot(name)
     for k, v in kw.items():
