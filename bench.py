@@ -433,7 +433,7 @@ def main():
                          "kernel_ms_note": "kernel_ms: HIP events around the timed steps on the launch stream / steps; "
                                            "back_to_back: the same kernel alone, 100 launches",
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "note": "metric asks for the HBM fraction; the kernel is FP32-VALU bound, see `valu`"},
+                         "note": "metric asks for the HBM fraction; the kernel is instruction-issue bound (FP32 VALU pipe, issue slots of the solver sweeps), see `valu` and DESIGN.md section 4"},
             "valu": {"achieved": ach_tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / VALU_PEAK_TFLOPS,
                      "algorithmic_flops_per_env_step": flops_step},
         }
