@@ -212,6 +212,18 @@ def test_parity_bookkeeping_helpers():
     fp.add(7, 2e-3, spread=wide)
     with pytest.raises(AssertionError):
         fp.report("unit")                    # two explained outliers among 302 contact samples: one too many
+    fq = FloatParity(1e-4, 0.03)             # beyond a tolerance by LESS than the oracle's own spread: counted apart, bounded at 2 %
+    for _ in range(100):
+        fq.add(4, 2e-6, 1e-3)
+    fq.add(5, 5e-4, 0.1, spread=wide); fq.add(5, 9e-4, 0.19, spread=wide)
+    assert fq.noisy == 2 and fq.outliers == []
+    fq.report("unit")
+    fq.add(5, 6e-4, 0.1, spread=wide); fq.add(5, 6e-4, 0.1, spread=wide)
+    with pytest.raises(AssertionError):
+        fq.report("unit")                    # 4 > max(2, 2 % of 104)
+    ff = FloatParity(1e-4, explain_contact_free=True)      # the fuzzers' mode: a contact-free sample may be explained too
+    ff.add(0, 2e-4, spread=dict(q=1e-4, base=0.0, qd=0.0, tau_rel=0.0))
+    assert len(ff.outliers) == 1
     with pytest.raises(AssertionError):
         FloatParity(1e-4).add(3, 5e-4, spread=steady)      # beyond the tolerance and NOT explained: this is what a kernel bug looks like
     with pytest.raises(AssertionError):

@@ -40,13 +40,13 @@ N_ENVS, N_STEPS = 5, 40
 
 class Totals:
     def __init__(self):
-        self.cases = self.samples = self.contact_samples = self.outliers = 0
+        self.cases = self.samples = self.contact_samples = self.outliers = self.noisy = 0
         self.clamp = self.dup = self.tie = self.fk = 0
         self.ill = []
 
     def line(self):
         return (f"{self.cases} cases stepped ({self.samples} samples compared, {self.contact_samples} of them with contacts, "
-                f"{self.outliers} counted outliers, {len(self.ill)} ill-conditioned; not compared: {self.clamp} at the velocity clamp or "
+                f"{self.outliers} counted outliers, {self.noisy} more beyond a tolerance but within the oracle's own spread, {len(self.ill)} ill-conditioned; not compared: {self.clamp} at the velocity clamp or "
                 f"diverged, {self.dup} with duplicate link-link contacts, {self.tie} with a joint at a bound between substeps; "
                 f"link poses of {self.fk} states equal to the oracle's forward kinematics)")
 
@@ -71,7 +71,7 @@ def _ulp_nudge(x64, rng):
 
 
 def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, tol=2e-4, base_vel=0.3, urdf=None, base_cmd=None, n_envs=None, n_steps=None,
-             min_allowed=1):
+             min_allowed=3):
     """Steps one case; raises AssertionError (after printing what it knows) on a failure."""
     n = model.n_links
     N_ENVS = n_envs or globals()["N_ENVS"]
@@ -88,7 +88,9 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     # q [rad]; qd [rad/s] (q error = dt * qd error); motor torque relative to max(1, largest torque).  A contact force is
     # m erp depth / dt^2: the 1e-7 m that chained FP32 transforms leave in a sphere centre are 0.1 N on a 28 kg Pepper at
     # dt = 1/480, 2 % of its hip torque with the angles equal to 1e-7 rad -- the torque tolerance follows 1 / dt^2
-    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed)
+    # (explained outliers cluster: a config that is ill-conditioned is so on every step, so the per-case cap is max(3, 0.3 %) here
+    #  where the tests use max(1, 0.3 %); each one must still be explained on its own)
+    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed, explain_contact_free=True, noisy_frac=0.1)
     lim_idx = np.flatnonzero(model.limited)
     vlim = 0.9 * (min(cfg.max_coord_velocity, 100.0) if cfg.max_coord_velocity > 0 else 100.0)
     fast = lambda st: (np.abs(st[:, 7:13]).max(1) > vlim) | (np.abs(st[:, 13 + n:13 + 2 * n]).max(1) > vlim)
@@ -103,6 +105,51 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
         q2 = g2.step(torch.tensor(act, dtype=torch.float32, device="cuda:0"), joint_sel=sel, n_substeps=n_sub)[0].cpu().numpy()
         g2.close()
         return o2, q2
+
+    def sweep_sensitivity(e, state, a2, sel2, n_sub):
+        """How far the oracle's own answer moves with ONE sweep more or fewer (rad, rad/s): where the sweeps have settled into a
+        limit cycle instead of converging (deeply interpenetrating link-link contacts under friction), the answer after a
+        FIXED number of sweeps is not a function of the state that any arithmetic could agree on."""
+        import dataclasses
+        out = []
+        for it in (cfg.solver_iters - 1, cfg.solver_iters, cfg.solver_iters + 1):
+            c2 = OracleSim(model, dataclasses.replace(cfg, solver_iters=max(it, 0)), N_ENVS)
+            c2.state[:] = state
+            c2.step(a2, joint_sel=sel2, n_substeps=n_sub, base_cmd=base_cmd)
+            out.append(c2.state[e].copy())
+        dq = max(np.abs(out[k][13:13 + n] - out[1][13:13 + n]).max() for k in (0, 2))
+        dqd = max(np.abs(out[k][13 + n:13 + 2 * n] - out[1][13 + n:13 + 2 * n]).max() for k in (0, 2))
+        return float(dq), float(dqd)
+
+    def substeps_consistent(e, state0):
+        """Several substeps: is every SINGLE substep, each from a state shared by both sides (the kernel's own, rounded to
+        float32), within the tolerances or explained by the oracle's spread?  Then the difference after all of them is the
+        oracle's own dynamics amplifying a within-tolerance difference (contacts make them chaotic), not an error."""
+        state = state0.astype(np.float32).astype(np.float64)
+        for s2 in range(sub):
+            a2, sel2 = (act, sel) if s2 == 0 else (None, None)
+            walk.state[:] = state
+            walk.step(a2, joint_sel=sel2, n_substeps=1, base_cmd=base_cmd)
+            g2 = HgSim(model, cfg, N_ENVS, "cuda:0")
+            if base_cmd is not None:
+                g2.set_base_velocity(torch.tensor(base_cmd, dtype=torch.float32))
+            g2.set_state(torch.tensor(state, dtype=torch.float32))
+            g2.step(None if a2 is None else torch.tensor(a2, dtype=torch.float32, device="cuda:0"), joint_sel=sel2, n_substeps=1)
+            ks = g2.get_state().cpu().numpy().astype(np.float64)
+            g2.close()
+            dq = float(np.abs(ks[e, 13:13 + n] - walk.state[e, 13:13 + n]).max())
+            dqd = float(np.abs(ks[e, 13 + n:13 + 2 * n] - walk.state[e, 13 + n:13 + 2 * n]).max())
+            t_q, t_qd = max(fp.tol[0] / sub, 1e-4), max(fp.tol[1] / sub, 0.03)      # the one-step bars of the tests
+            if not (dq < t_q and dqd < t_qd):
+                sp = walk.noise_spread(state[e], None if a2 is None else a2[e], joint_sel=sel2, n_substeps=1,
+                                       base_cmd_row=None if base_cmd is None else base_cmd[e], trials=64)
+                if dq > max(6.0 * float(np.max(sp["q"])), t_q) or dqd > max(6.0 * float(np.max(sp["qd"])), t_qd):
+                    sq, sqd = sweep_sensitivity(e, state, a2, sel2, 1)
+                    if sq > dq / 6.0 or sqd > dqd / 6.0:
+                        return True, f"substep {s2}: one sweep more or fewer moves the oracle by {sq:.3g} rad, {sqd:.3g} rad/s (kernel - oracle {dq:.3g}, {dqd:.3g})"
+                    return False, f"substep {s2}: {dq:.3g} rad, {dqd:.3g} rad/s from a shared state (oracle spread {float(np.max(sp['q'])):.3g}, {float(np.max(sp['qd'])):.3g})"
+            state = ks
+        return True, "every substep agrees from a shared state"
 
     def dump_sample(sub_dir, e, before, o, gq):
         dump = os.environ.get("FUZZ_DUMP")
@@ -228,6 +275,22 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                 try:
                     fp.add(nce, *vals, spread=spread)
                 except AssertionError as err:
+                    if sub == 1 and "UNEXPLAINED" in str(err):
+                        sq, sqd = sweep_sensitivity(e, before, act, sel, 1)
+                        if sq > vals[0] / 6.0 or sqd > vals[1] / 6.0:
+                            fp.n -= 1; fp.n_contact -= 1 if nce > 0 else 0
+                            ip.total -= 1; ip.same -= 1
+                            tot.ill.append((tag.split(":")[0], nce, "%.3g rad, %.3g rad/s, torque %.3g" % vals, "",
+                                            "one sweep more or fewer moves the oracle by %.3g rad, %.3g rad/s" % (sq, sqd)))
+                            continue
+                    if sub > 1 and "UNEXPLAINED" in str(err):
+                        fp.n -= 1; fp.n_contact -= 1 if nce > 0 else 0
+                        ok, why = substeps_consistent(e, before)
+                        if ok:
+                            ip.total -= 1; ip.same -= 1
+                            tot.ill.append((tag.split(":")[0], nce, "%.3g rad, %.3g rad/s, torque %.3g" % vals, " after %d substeps" % sub, why))
+                            continue
+                        fail(e, t, str(err) + "; " + why, before, o, gq)
                     fail(e, t, str(err), before, o, gq)
                 if len(fp.outliers) > n_out:
                     print(f"  explained outlier: {tag.split(':')[0]} step {t} env {e}, {nce} contacts: %.3g rad, %.3g rad/s, torque %.3g (relative)" % vals
@@ -256,5 +319,5 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     except AssertionError as err:
         print("FAILED", tag, err)
         raise AssertionError("fuzz failure (details printed above): " + tag)
-    tot.cases += 1; tot.samples += fp.n; tot.outliers += len(fp.outliers); tot.contact_samples += fp.n_contact
+    tot.cases += 1; tot.samples += fp.n; tot.outliers += len(fp.outliers); tot.noisy += fp.noisy; tot.contact_samples += fp.n_contact
     gpu.close()

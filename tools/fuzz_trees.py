@@ -44,9 +44,9 @@ def run(n_cases=60, seed=1):
         for k, v in over.items():
             setattr(cfg, k, v)
         try:
-            # a light link under a heavy subtree: the articulated inertia's rank-one downdate cancels and float32 loses three
-            # digits there; such samples must still be EXPLAINED by the oracle's spread, but up to 3 per case may occur
-            run_case(tot, tag, model, cfg, sub, rng, -1.0, 1.0, model.n_act, tol=2e-4, base_vel=0.5, urdf=path, min_allowed=3 if scaled else 1)
+            # (scaled: a light link under a heavy subtree -- the articulated inertia's rank-one downdate cancels and float32 loses
+            #  three digits there; such samples must still be EXPLAINED by the oracle's spread: fuzz_common.py)
+            run_case(tot, tag, model, cfg, sub, rng, -1.0, 1.0, model.n_act, tol=2e-4, base_vel=0.5, urdf=path)
         except HgError as e:
             print(tag, "-> refused:", str(e)[:100]); refused += 1; continue
         dual += int(model.n_links + 3 * cfg.max_contacts > 64); sizes.append(model.n_links)
