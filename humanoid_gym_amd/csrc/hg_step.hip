@@ -1710,12 +1710,23 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         constexpr bool LIM_SCAN = NMX > 48;
         const unsigned lim_lo32 = (unsigned)limmask, lim_hi32 = (unsigned)(limmask >> 32);
         auto sweep2 = [&](const bool forward) {
+            // the mask words are made opaque per sweep: hipcc would otherwise hoist every joint's bit test out of the sweep loop as a
+            // 64-bit condition mask, 61 SGPR pairs that it then parks in VGPR lanes and reads back with two v_readlane per test
+            unsigned lo32 = lim_lo32, hi32 = lim_hi32;
+            asm volatile("" : "+s"(lo32), "+s"(hi32));
             if (forward) {
                 if constexpr (LIM_SCAN) {
                     if (limmask != 0ull) {
+                        // (groups of 8 joints under one test of their mask byte: the violated joints are the fingers, neighbours in
+                        //  the joint order, so most groups are skipped with one test instead of eight)
 #pragma unroll
-                        for (int i = 0; i < NMX; ++i)
-                            if (((i < 32 ? lim_lo32 : lim_hi32) >> (i & 31)) & 1u) limit_update_at(i);
+                        for (int g = 0; g < NMX; g += 8) {
+                            if (((g < 32 ? lo32 : hi32) >> (g & 31)) & 0xffu) {
+#pragma unroll
+                                for (int i = g; i < g + 8; ++i)
+                                    if (i < NMX && (((i < 32 ? lo32 : hi32) >> (i & 31)) & 1u)) limit_update_at(i);
+                            }
+                        }
                     }
                 } else {
                     #pragma unroll 1
@@ -1727,8 +1738,13 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
                 if constexpr (LIM_SCAN) {
                     if (limmask != 0ull) {
 #pragma unroll
-                        for (int i = NMX - 1; i >= 0; --i)
-                            if (((i < 32 ? lim_lo32 : lim_hi32) >> (i & 31)) & 1u) limit_update_at(i);
+                        for (int g = (NMX - 1) / 8 * 8; g >= 0; g -= 8) {
+                            if (((g < 32 ? lo32 : hi32) >> (g & 31)) & 0xffu) {
+#pragma unroll
+                                for (int i = g + 7; i >= g; --i)
+                                    if (i < NMX && (((i < 32 ? lo32 : hi32) >> (i & 31)) & 1u)) limit_update_at(i);
+                            }
+                        }
                     }
                 } else {
                     #pragma unroll 1
