@@ -234,6 +234,8 @@ def main():
     is_nao = args.robot in ("nao", "nao_hands")
     if is_nao and not any(kv.startswith("store_torques=") for kv in args.cfg):
         cfg.store_torques = False      # as NaoEnv (envs/softbank_envs.py): nothing on this path reads getJointState()[3]
+    if is_nao and not any(kv.startswith("store_contacts=") for kv in args.cfg):
+        cfg.store_contacts = False     # ... nor getContactPoints (the `collision` flag is written either way)
     if is_nao:
         rows, sel = synthetic_replay(model)
         if args.robot == "nao_hands":
@@ -248,6 +250,8 @@ def main():
     else:
         from humanoid_gym_amd._capi import HgSim
         sim = HgSim(model, cfg, n_envs, dev)
+        if is_nao:
+            sim.obs_qd = None          # NaoEnv's observation is the joint positions only (nao_env.py:73-79)
     # actions for every (time, env) resident in HBM: [T, n_envs, n_sel]
     first_env = rank * n_envs
     phase = (torch.arange(n_envs, device=dev) + first_env) % T_TRAJ
@@ -329,7 +333,15 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     kernel_ms_b2b = ev0.elapsed_time(ev1) / kreps
-    _, counts, _ = sim.contact_pairs()
+    if cfg.store_contacts:
+        _, counts, _ = sim.contact_pairs()
+    else:       # the timed handle keeps no contact lists: one more step of a copy that does, from the same state
+        import dataclasses
+        chk = HgSim(model, dataclasses.replace(cfg, store_contacts=True), n_envs, dev)
+        chk.set_state(sim.get_state())
+        chk.step(actions[kreps % T_TRAJ], joint_sel=sel, n_substeps=1)
+        _, counts, _ = chk.contact_pairs()
+        chk.close()
     mean_contacts = float(counts.float().mean().item())
 
     # Beside the headline: the same envs as G handles on G streams, not joined between steps
@@ -371,9 +383,10 @@ def main():
     if args.robot == "nao_hands" and not args.cfg and world == 1 and os.environ.get("HG_BENCH_SMALL", "1") != "0":
         try:
             hmodel, hcfg = load_robot("nao")
-            hcfg.store_torques = cfg.store_torques
+            hcfg.store_torques, hcfg.store_contacts = cfg.store_torques, cfg.store_contacts
             hrows, hsel = synthetic_replay(hmodel)
             hsim = HgSim(hmodel, hcfg, n_envs, dev)
+            hsim.obs_qd = None
             hrows_d = torch.tensor(hrows, device=dev)
             hact = torch.stack([hrows_d[(t + phase) % T_TRAJ] for t in range(T_TRAJ)]).contiguous()
             for t in range(args.warmup):
@@ -425,7 +438,7 @@ def main():
                        if is_nao else f"{args.robot} random targets",
                        "robot": model.name + ("_like (stand-in URDF" + (", with the finger joints of the hands" if args.robot.endswith("_hands") else "") + ")" if args.robot != "dancer" else ""),
                        "constraint_rows": model.n_links + 3 * cfg.max_contacts, "action_columns": int(len(sel)),
-                       "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters, "motor_torques_stored": bool(cfg.store_torques),
+                       "envs_per_gpu": n_envs, "n_dof": model.n_links, "solver_iters": cfg.solver_iters, "motor_torques_stored": bool(cfg.store_torques), "contact_lists_stored": bool(cfg.store_contacts),
                        "mean_contacts": mean_contacts, "state_finite": finite, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -25,7 +25,7 @@ SYMBOLS = ["hg_last_error", "hg_abi_version", "hg_create", "hg_destroy", "hg_res
 
 
 # the ABI version that the ctypes mirrors in model.py (HgModel, HgConfig) and the prototypes below are written for
-HG_ABI_VERSION = 7
+HG_ABI_VERSION = 8
 
 
 class HgError(RuntimeError):
@@ -191,6 +191,8 @@ class HgSim:
         return cp, cq, fp, fq
 
     def contact_pairs(self):
+        """(pairs [n_envs, HG_MAX_CONTACTS, 2], counts [n_envs], link mask [n_envs]) of the last physics step;
+        HgError on a simulator created with store_contacts=False."""
         t = self.torch
         pairs = t.empty(self.n_envs, HG_MAX_CONTACTS, 2, dtype=t.int32, device=self.device)
         counts = t.empty(self.n_envs, dtype=t.int32, device=self.device)

@@ -476,7 +476,7 @@ using namespace hg;
 extern "C" {
 
 const char *hg_last_error(void) { return g_err.c_str(); }
-int hg_abi_version(void) { return 7; }
+int hg_abi_version(void) { return 8; }
 
 #ifdef HG_PHASE_TIMING
 // diagnostics build only (tools/phase_ticks.py): the shader-clock stamps of the last launch (of the variant launched last)
@@ -570,15 +570,17 @@ int hg_create(const hg_model *model, const hg_config *config, int n_envs, int de
     hipError_t e = hipMalloc(&s->d_model, sizeof(DevModel));
     if (e == hipSuccess) e = hipMalloc(&s->d_state, sizeof(float) * (size_t)n_envs * s->state_stride);
     if (e == hipSuccess) e = hipMemset(s->d_state, 0, sizeof(float) * (size_t)n_envs * s->state_stride);
-    if (e == hipSuccess) e = hipMalloc(&s->d_link_mask, sizeof(unsigned long long) * (size_t)n_envs);
-    if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
-    if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
+    if (config->store_contacts) {
+        if (e == hipSuccess) e = hipMalloc(&s->d_link_mask, sizeof(unsigned long long) * (size_t)n_envs);
+        if (e == hipSuccess) e = hipMalloc(&s->d_pairs, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
+        if (e == hipSuccess) e = hipMalloc(&s->d_counts, sizeof(int32_t) * (size_t)n_envs);
+    }
     if (e == hipSuccess) e = hipMalloc(&s->d_cum, sizeof(float) * 4 * (size_t)n_envs);
     if (e == hipSuccess && config->store_torques) e = hipMalloc(&s->d_torque, sizeof(float) * (size_t)n_envs * n);
     if (e == hipSuccess) e = hipMemcpy(s->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
-    if (e == hipSuccess) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
-    if (e == hipSuccess) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
+    if (e == hipSuccess && s->d_pairs) e = hipMemset(s->d_link_mask, 0, sizeof(unsigned long long) * (size_t)n_envs);
+    if (e == hipSuccess && s->d_pairs) e = hipMemset(s->d_pairs, 0xFF, sizeof(int32_t) * (size_t)n_envs * HG_MAX_CONTACTS * 2);
+    if (e == hipSuccess && s->d_pairs) e = hipMemset(s->d_counts, 0, sizeof(int32_t) * (size_t)n_envs);
     if (e == hipSuccess) e = hipMemset(s->d_cum, 0, sizeof(float) * 4 * (size_t)n_envs);
     if (e == hipSuccess && s->d_torque) e = hipMemset(s->d_torque, 0, sizeof(float) * (size_t)n_envs * n);
     delete hm;
@@ -717,6 +719,7 @@ int hg_get_link_states(hg_sim *s, float *com_pos_dev, float *com_quat_dev, float
 int hg_get_contact_pairs(hg_sim *s, int32_t *pairs_dev, int32_t *counts_dev, uint64_t *link_mask_dev, void *stream) {
     if (!s) return fail(HG_EINVAL, "hg_get_contact_pairs: null handle");
     HG_DEVICE(s);
+    if (!s->d_pairs) return fail(HG_EINVAL, "hg_get_contact_pairs: this handle was created with store_contacts = 0");
     const size_t tot = (size_t)s->n_envs * HG_MAX_CONTACTS * 2;
     hipLaunchKernelGGL(copy_contacts_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        s->d_pairs, s->d_counts, s->d_link_mask, pairs_dev, counts_dev,

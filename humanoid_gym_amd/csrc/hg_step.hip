@@ -1934,7 +1934,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
     {
         int a = -3, b = -3;
         if (lane < nc) { a = __float_as_int(conL[CON * lane]); b = __float_as_int(conL[CON * lane + 1]); }
-        if (lane < HG_MAX_CONTACTS) {
+        if (O.pairs && lane < HG_MAX_CONTACTS) {
             O.pairs[((size_t)env * HG_MAX_CONTACTS + lane) * 2] = a;
             O.pairs[((size_t)env * HG_MAX_CONTACTS + lane) * 2 + 1] = b;
         }
@@ -1946,8 +1946,7 @@ void hg_step_kernel(const DevModel *__restrict__ M, const StepParams P, float *_
         link_mask = ((unsigned long long)bhi << 32) | blo;   // valid on lanes 0..15
     }
     if (lane == 0) {
-        O.link_mask[env] = link_mask;
-        O.counts[env] = nc;
+        if (O.pairs) { O.link_mask[env] = link_mask; O.counts[env] = nc; }      // (store_contacts = 0: none of the three)
         if (O.collision) O.collision[env] = (link_mask >> 1) != 0ull ? 1 : 0;
         if (O.reward) O.reward[env] = 0.f;
         if (O.done) O.done[env] = any_bad ? 1 : 0;

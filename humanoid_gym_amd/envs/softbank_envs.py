@@ -35,6 +35,9 @@ class _SoftbankEnv(BatchedHumanoidEnv):
         # caller of these envs reads getJointState()[3], so the step does not store the motor torques (4 n bytes per env
         # and physics step less written); store_torques=True as an override brings sim.joint_torques() back
         cfg.store_torques = False
+        # ... nor getContactPoints: the link pairs / counts / link masks (108 B per env) stay unstored as well
+        # (store_contacts=True brings sim.contact_pairs() back; the per-env `collision` flag is written either way)
+        cfg.store_contacts = False
         for k, v in cfg_overrides.items():
             setattr(cfg, k, v)
         super().__init__(model, cfg, n_envs, device, n_substeps, auto_reset)
@@ -87,6 +90,7 @@ class NaoEnv(_SoftbankEnv):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         assert self.joint_names == NAO_JOINTS                          # nao_env.py:30-31
+        self.sim.obs_qd = None       # the observation is the 22 positions (nao_env.py:73-79): hg_step gets no velocity buffer
         self.action_space = spaces.Box(np.array(self.lower_limits, dtype=np.float32),
                                        np.array(self.upper_limits, dtype=np.float32))
 

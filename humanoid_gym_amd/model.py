@@ -90,7 +90,7 @@ class HgConfig(C.Structure):
         ("limit_max_impulse", C.c_double),
         ("residual_threshold", C.c_double),
         ("store_torques", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("store_contacts", C.c_int32),
     ]
 
 
@@ -120,6 +120,7 @@ class SimConfig:
     residual_threshold: float = 0.0      # > 0: leave the sweep loop once a sweep's largest squared velocity residual is <= this
                                          # (PyBullet's solverResidualThreshold default is 1e-7 [UPSTREAM-RECALL]); 0: every sweep
     store_torques: bool = True           # keep the applied motor torques of each physics step for joint_torques()
+    store_contacts: bool = True          # keep the contact link pairs / counts / link masks of each step for contact_pairs()
 
     def to_c(self) -> HgConfig:
         c = HgConfig()
@@ -140,6 +141,7 @@ class SimConfig:
         c.limit_max_impulse = self.limit_max_impulse
         c.residual_threshold = float(self.residual_threshold)
         c.store_torques = int(self.store_torques)
+        c.store_contacts = int(self.store_contacts)
         return c
 
 

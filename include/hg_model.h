@@ -122,7 +122,9 @@ typedef struct hg_config {
                                   reference sets only the iteration count, dancer_env.py:64).  0: all solver_iters sweeps */
     int32_t store_torques;     /* 1: the applied motor torques of every physics step are kept for hg_get_joint_torques
                                   (getJointState()[3], dancer_env.py:24); 0: not stored, the getter fails             */
-    int32_t reserved0;
+    int32_t store_contacts;    /* 1: the contact link pairs, their count and the per-env link mask of the last physics step
+                                  are kept for hg_get_contact_pairs (getContactPoints, dancer_env.py:32-39); 0: not
+                                  stored, the getter fails (the `collision` flag of hg_step is written either way)  */
 } hg_config;
 
 /* State record of one env: HG_STATE_BASE + 3*n values (double in the oracle,

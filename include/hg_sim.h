@@ -45,7 +45,8 @@ const char *hg_last_error(void);
 /* Library/ABI version, bumped on any signature or struct-layout change (3: hg_model.joint_limited,
  * hg_config.max_coord_velocity / enable_limits / limit_max_impulse, hg_stats_flush, hg_set_base_velocity;
  * 4: hg_get_joint_torques; 5: HG_MAX_LINKS 48 -> 62 (hg_model layout), hg_stats_accumulate_noalloc;
- * 6: hg_config.residual_threshold / store_torques; 7: hg_model.sphere_half, HG_MAX_SPHERES 1024).  A binding must compare it with the version its struct mirrors
+ * 6: hg_config.residual_threshold / store_torques; 7: hg_model.sphere_half, HG_MAX_SPHERES 1024;
+ * 8: hg_config.store_contacts in the place of the reserved word).  A binding must compare it with the version its struct mirrors
  * were written for before it hands a struct to the library (humanoid_gym_amd/_capi.py does). */
 int hg_abi_version(void);
 
@@ -130,7 +131,7 @@ int hg_get_link_states(hg_sim *sim, float *com_pos_dev, float *com_quat_dev,
  *              base = -1, ground plane = -2, unused slot = -3
  *   counts_dev [n_envs] int32 number of used slots
  *   link_mask_dev [n_envs] uint64, bit b set = body b-1 has a contact
- * All nullable.
+ * All nullable.  HG_EINVAL on a handle created with hg_config.store_contacts = 0 (the step then keeps none of the three).
  */
 int hg_get_contact_pairs(hg_sim *sim, int32_t *pairs_dev, int32_t *counts_dev,
                          uint64_t *link_mask_dev, void *stream);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert getattr(L, n) is not None
     from humanoid_gym_amd._capi import HG_ABI_VERSION
-    assert L.hg_abi_version() == HG_ABI_VERSION == 7
+    assert L.hg_abi_version() == HG_ABI_VERSION == 8
 
 
 def test_struct_sizes_match_header():

@@ -630,3 +630,42 @@ def test_store_torques_off_changes_nothing_but_the_getter():
     on.close(); off.close()
     env = hg.make("nao-v0", n_envs=2)
     assert env.sim.cfg.store_torques is False and hg.make("dancer-v0", n_envs=2).sim.cfg.store_torques is True
+
+
+@pytest.mark.gpu
+def test_store_contacts_off_and_no_velocity_buffer_change_nothing_else():
+    """hg_config.store_contacts = 0 and a NULL obs_qd_dev (what NaoEnv and the bench hand over: the reference's NAO
+    observation is the joint positions, nao_env.py:73-79, and nothing there calls getContactPoints): every other output
+    and the state are bit-identical, the `collision` flag included; hg_get_contact_pairs fails loudly."""
+    import torch
+    import humanoid_gym_amd as hg
+    import dataclasses
+    from humanoid_gym_amd._capi import HgError, HgSim
+    n_envs = 6
+    model, cfg = load_robot("nao_hands")
+    on = HgSim(model, cfg, n_envs, "cuda:0")
+    off = HgSim(model, dataclasses.replace(cfg, store_contacts=False), n_envs, "cuda:0")
+    off.obs_qd = None
+    rng = np.random.default_rng(3)
+    seen = 0
+    for t in range(12):
+        act = torch.tensor(rng.uniform(-0.5, 0.5, (n_envs, model.n_act)).astype(np.float32), device="cuda:0")
+        a, b = on.step(act), off.step(act)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        assert torch.equal(on.base_xyyaw, off.base_xyyaw)
+        seen += int(off.collision.sum())
+    assert seen > 0                                            # the flag is live without the lists
+    assert torch.equal(on.get_state(), off.get_state())
+    assert int(on.contact_pairs()[1].sum()) > 0
+    with pytest.raises(HgError, match="store_contacts"):
+        off.contact_pairs()
+    on.close(); off.close()
+    nao, pepper = hg.make("nao-v0", n_envs=2), hg.make("pepper-v0", n_envs=2)
+    assert nao.sim.cfg.store_contacts is False and nao.sim.obs_qd is None
+    assert pepper.sim.cfg.store_contacts is False and pepper.sim.obs_qd is not None      # pepper_env.py:67: velocities are observed
+    obs, _, _, _ = nao.step(np.asarray(nao.init_angles, np.float32))
+    assert np.isfinite(np.asarray(obs.cpu() if hasattr(obs, "cpu") else obs)).all()
+    dancer = hg.make("dancer-v0", n_envs=2)
+    assert dancer.sim.cfg.store_contacts is True
+    dancer.step(np.zeros(18, np.float32)); dancer.contact_pairs()

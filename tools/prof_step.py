@@ -21,11 +21,14 @@ if rand or replay:
     rest.pop(0)
 model, cfg = load_robot(robot)
 if replay:
-    cfg.store_torques = False      # as bench.py / NaoEnv: nothing on that path reads the motor torques
+    cfg.store_torques = False      # as bench.py / NaoEnv: nothing on that path reads the motor torques,
+    cfg.store_contacts = False     # the contact lists
 for kv in rest:
     k, v = kv.split("=")
     setattr(cfg, k, type(getattr(cfg, k))(ast.literal_eval(v)))
 sim = HgSim(model, cfg, n_envs, "cuda:0")
+if replay:
+    sim.obs_qd = None              # or the joint velocities
 rng = np.random.default_rng(4)
 acts = None
 if replay:
