@@ -53,26 +53,40 @@ class _SoftbankEnv(BatchedHumanoidEnv):
         for child, (parent, mult, off) in (model.meta.get("mimic") or {}).items():
             if child in model.dof_names and parent in model.dof_names:
                 self._mimic.setdefault(parent, []).append((model.dof_of(child), float(mult), float(off)))
+        self._plans = {}      # joint-name tuple -> action-column plan (_column_plan)
         n = len(self.joint_names)
         self.observation_space = spaces.Box(np.array([-1] * n, dtype=np.float32), np.array([1] * n, dtype=np.float32))
+
+    def _column_plan(self, names):
+        """(dof indices of the action columns, source column / multiplier / offset tensors or None) for a list of joint
+        names: the columns given, then one column per <mimic> follower of a named joint that is not named itself."""
+        sel = [self.model.dof_of(j) for j in names]
+        src, mult, off = list(range(len(sel))), [1.0] * len(sel), [0.0] * len(sel)
+        for c, j in enumerate(names):
+            for dof, m, o in self._mimic.get(j, ()):
+                if dof not in sel:
+                    sel.append(dof); src.append(c); mult.append(m); off.append(o)
+        if len(sel) == len(names):
+            return np.asarray(sel, np.int32), None
+        t = self._torch
+        f = lambda v: t.tensor(v, dtype=t.float32, device=self.device)      # noqa: E731
+        return np.asarray(sel, np.int32), (t.tensor(src, dtype=t.int64, device=self.device), f(mult), f(off))
 
     def _step_sim(self, actions, joints=None):
         names = self.joint_names if joints is None else list(joints)
         if joints is None and not self._mimic:
             a = self._actions_tensor(actions, len(names))
             return self.sim.step(a, n_substeps=self.n_substeps)
-        sel = [self.model.dof_of(j) for j in names]
-        a = self._actions_tensor(actions, len(sel))
-        if self._mimic:
-            extra, cols = [], []
-            for c, j in enumerate(names):
-                for dof, mult, off in self._mimic.get(j, ()):
-                    if dof not in sel and dof not in extra:
-                        extra.append(dof)
-                        cols.append(a[:, c] * mult + off)
-            if extra:
-                a = self._torch.cat([a, self._torch.stack(cols, dim=1)], dim=1).contiguous()
-                sel = sel + extra
+        key = tuple(names)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 64:      # callers that keep inventing joint lists do not grow the cache for ever
+                self._plans.clear()
+            plan = self._plans[key] = self._column_plan(names)
+        sel, cols = plan
+        a = self._actions_tensor(actions, len(names))
+        if cols is not None:      # one gather and one fused multiply-add: follower = multiplier * parent + offset (x 1 + 0 for the rest)
+            a = self._torch.addcmul(cols[2], a.index_select(1, cols[0]), cols[1])
         return self.sim.step(a, joint_sel=sel, n_substeps=self.n_substeps)
 
     def _dict_obs(self):

@@ -236,6 +236,15 @@ def test_parity_bookkeeping_helpers():
         FloatParity(1e-4).add(3, 0.5, spread=wide)        # beyond the bound
     with pytest.raises(AssertionError):
         FloatParity(1e-4).add(3, float("nan"))
+    # the fuzzers' mode: within the oracle's OWN spread the spread is the bound; a marginal explanation stays under `bound`
+    chaotic = dict(q=0.135, base=0.03, qd=32.0, tau_rel=2.0)
+    fz = FloatParity(2e-4, bound_within_own_spread=False)
+    fz.add(3, 0.058, spread=chaotic)
+    assert fz.noisy == 1 and fz.outliers == []
+    with pytest.raises(AssertionError):
+        fz.add(3, 0.058, spread=dict(q=0.02, base=0.0, qd=5.0, tau_rel=0.1))      # 2.9x the spread: marginal, and beyond the bound
+    with pytest.raises(AssertionError):
+        FloatParity(2e-4).add(3, 0.058, spread=chaotic)                           # the tests keep the bound for every sample
 
     class _Cpu:
         n_envs = 2

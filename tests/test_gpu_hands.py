@@ -201,6 +201,12 @@ def test_hands_envs_and_full_size_invariants():
     n = nao.model.n_links
     tgt = nao.sim.get_state()[:, 13 + 2 * n:].cpu().numpy()
     assert abs(tgt[0, nao.model.dof_of("LFinger11")] - 0.95 * 0.8) < 1e-6
+    # the column plan of a joint list is built once; a follower that is named itself takes its own column
+    nao.step(torch.full((4, 2), 0.5, device="cuda:0"), joints=["LHand", "RHand"])
+    assert len(nao._plans) == 2                                                             # all 22 joints, (LHand, RHand)
+    nao.step(torch.tensor([[0.5, 0.1]] * 4, device="cuda:0"), joints=["LHand", "LFinger11"])
+    tgt = nao.sim.get_state()[:, 13 + 2 * n:].cpu().numpy()
+    assert abs(tgt[0, nao.model.dof_of("LFinger11")] - 0.1) < 1e-6 and abs(tgt[0, nao.model.dof_of("LFinger12")] - 0.95 * 0.5) < 1e-6
     nao.close()
     rom = hg.make("romeo-v0", n_envs=2, hands=True)
     assert rom.model.n_links == 61 and len(rom.joint_names) == 37 and not any("Finger" in j or "Thumb" in j for j in rom.joint_names)

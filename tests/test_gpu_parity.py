@@ -81,7 +81,12 @@ EXPLAIN_EPS = 1e-6
 
 
 class FloatParity:
-    def __init__(self, tol_q, tol_qd=None, tol_tau=None, bound=0.05, min_allowed=1, explain_contact_free=False, noisy_frac=0.02):
+    def __init__(self, tol_q, tol_qd=None, tol_tau=None, bound=0.05, min_allowed=1, explain_contact_free=False, noisy_frac=0.02,
+                 bound_within_own_spread=True):
+        # the fuzzers switch this off: a sample whose ORACLE answer moves by more than the kernel differs is bounded by that
+        # spread, not by `bound` (tools/fuzz_fail/r3more4_tree435: two interpenetrating links of a 40-link tree at 20 rad/s
+        # under 7 sweeps; kernel - oracle 0.058 rad where the oracle spreads by 0.135 rad under 1e-8 relative noise)
+        self.bound_within_own_spread = bound_within_own_spread
         self.noisy_frac = noisy_frac        # share of the samples that may differ by less than the oracle's own spread (fuzzers: 0.1,
                                             # one chaotic env of five fills a case with them)
         self.min_allowed = min_allowed      # the cap's floor: 1 in every test; the fuzzers (thousands of random configs) use 3
@@ -115,7 +120,7 @@ class FloatParity:
         bad = any(v is not None and t is not None and not (v < t) for v, t in zip(vals, self.tol))
         if bad:
             assert n_contacts > 0 or self.explain_contact_free, f"contact-free sample outside the tolerance: {vals} vs {self.tol}"
-            assert np.isfinite(dq) and dq < self.bound, f"outlier beyond the bound: |dq| = {dq}"
+            assert np.isfinite(dq) and (dq < self.bound or not self.bound_within_own_spread), f"outlier beyond the bound: |dq| = {dq}"
             if spread is None:
                 assert env is not None and self._ctx is not None, f"outlier {vals} with nothing to explain it by (call pre(), pass env=)"
                 spread = self.explain(env)
@@ -130,6 +135,7 @@ class FloatParity:
             if all(v is None or t is None or v < t or v <= s_ for v, t, s_ in zip(vals, self.tol, sp)):
                 self.noisy += 1
             else:
+                assert dq < self.bound, f"outlier beyond the bound: |dq| = {dq} (oracle's own spread {sp})"
                 self.outliers.append((int(n_contacts), float(dq)))
                 self.spreads.append(tuple(float(x) for x in sp))
         else:

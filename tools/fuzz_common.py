@@ -90,7 +90,8 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     # dt = 1/480, 2 % of its hip torque with the angles equal to 1e-7 rad -- the torque tolerance follows 1 / dt^2
     # (explained outliers cluster: a config that is ill-conditioned is so on every step, so the per-case cap is max(3, 0.3 %) here
     #  where the tests use max(1, 0.3 %); each one must still be explained on its own)
-    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed, explain_contact_free=True, noisy_frac=0.1)
+    fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed, explain_contact_free=True, noisy_frac=0.1,
+                     bound_within_own_spread=False)
     lim_idx = np.flatnonzero(model.limited)
     vlim = 0.9 * (min(cfg.max_coord_velocity, 100.0) if cfg.max_coord_velocity > 0 else 100.0)
     fast = lambda st: (np.abs(st[:, 7:13]).max(1) > vlim) | (np.abs(st[:, 13 + n:13 + 2 * n]).max(1) > vlim)
@@ -283,7 +284,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
                             tot.ill.append((tag.split(":")[0], nce, "%.3g rad, %.3g rad/s, torque %.3g" % vals, "",
                                             "one sweep more or fewer moves the oracle by %.3g rad, %.3g rad/s" % (sq, sqd)))
                             continue
-                    if sub > 1 and "UNEXPLAINED" in str(err):
+                    if sub > 1 and ("UNEXPLAINED" in str(err) or "beyond the bound" in str(err)):      # (8 substeps of chattering contacts: each substep is judged on its own)
                         fp.n -= 1; fp.n_contact -= 1 if nce > 0 else 0
                         ok, why = substeps_consistent(e, before)
                         if ok:
