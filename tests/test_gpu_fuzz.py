@@ -83,8 +83,8 @@ def test_launch_shapes_slice():
 def test_closed_loop_statistics_match_the_oracle():
     """Free-running rollouts separate trajectory by trajectory (contacts: chaos), so the closed-loop check is statistical:
     512 NAO envs x 240 steps on both sides with the same targets -- mean base height, joint-rate rms, collision rate and
-    contact count stay together and the final heights are one distribution (tools/rollout_stats.py; four robots at 1024 x
-    480 in profiles/round2_f_rollout_stats.txt).  A systematic bias of the FP32 kernel would show here."""
+    contact count stay together and the final heights are one distribution (tools/rollout_stats.py; six models at 1024 x
+    480 in profiles/round3_rollout_stats.txt).  A systematic bias of the FP32 kernel would show here."""
     import rollout_stats
     r = rollout_stats.rollout("nao", 512, 240)
     assert r["finite"] and r["ks_p"] > 1e-3, r

@@ -48,16 +48,17 @@ def rollout(robot, n_envs, n_steps, seed=0):
     return out
 
 
-def run(n_envs=1024, n_steps=480, robots=("nao", "pepper", "romeo", "dancer")):
+def run(n_envs=1024, n_steps=480, robots=("nao_hands", "romeo_hands", "nao", "pepper", "romeo", "dancer")):
     res = []
     for robot in robots:
         r = rollout(robot, n_envs, n_steps)
         res.append(r)
-        print(f"{robot:7s} {n_envs} envs x {n_steps} steps: final-height KS {r['ks_stat']:.3f} (p {r['ks_p']:.2f}); "
+        print(f"{robot:11s} {n_envs} envs x {n_steps} steps: final-height KS {r['ks_stat']:.3f} (p {r['ks_p']:.2f}); "
               + "; ".join(f"{k} {r[k]['kernel_last']:.4g} / {r[k]['oracle_last']:.4g} (worst gap {r[k]['worst_abs']:.2g})" for k in ("height", "qd_rms", "collision", "contacts")),
               flush=True)
     return res
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 480)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 480,
+        *([tuple(sys.argv[3:])] if len(sys.argv) > 3 else []))
