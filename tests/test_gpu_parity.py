@@ -82,7 +82,11 @@ EXPLAIN_EPS = 1e-6
 
 class FloatParity:
     def __init__(self, tol_q, tol_qd=None, tol_tau=None, bound=0.05, min_allowed=1, explain_contact_free=False, noisy_frac=0.02,
-                 bound_within_own_spread=True):
+                 bound_within_own_spread=True, noisy_cap=None):
+        # the fuzzers' floor under the cap of the samples within the oracle's own spread: ONE env's worth of samples per case (one env of the
+        # five that flails through a whole case -- interpenetrating links, most of its samples at the velocity clamp -- is
+        # noisy in every sample that is still compared: trees seed 129 case 45, 17 of the 81 compared samples of 200 stepped)
+        self.noisy_cap = noisy_cap
         # the fuzzers switch this off: a sample whose ORACLE answer moves by more than the kernel differs is bounded by that
         # spread, not by `bound` (tools/fuzz_fail/r3more4_tree435: two interpenetrating links of a 40-link tree at 20 rad/s
         # under 7 sweeps; kernel - oracle 0.058 rad where the oracle spreads by 0.135 rad under 1e-8 relative noise)
@@ -151,7 +155,7 @@ class FloatParity:
               f"explained outliers (n_contacts, |dq|): {self.outliers}, oracle spreads {self.spreads} (allowed {allowed}); "
               f"{self.noisy} more within the oracle's own spread")
         assert len(self.outliers) <= allowed, (self.outliers, allowed)
-        assert self.noisy <= max(2, int(np.ceil(self.noisy_frac * self.n))), (self.noisy, self.n)
+        assert self.noisy <= max(2, self.noisy_cap or 0, int(np.ceil(self.noisy_frac * self.n))), (self.noisy, self.n)
 
 
 def _mk(name, n_envs, **cfg_kw):

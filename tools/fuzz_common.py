@@ -91,7 +91,7 @@ def run_case(tot, tag, model, cfg, sub, rng, act_lo, act_hi, n_cols, sel=None, t
     # (explained outliers cluster: a config that is ill-conditioned is so on every step, so the per-case cap is max(3, 0.3 %) here
     #  where the tests use max(1, 0.3 %); each one must still be explained on its own)
     fp = FloatParity(tol, 300 * tol, 50 * tol * max(1.0, (1.0 / 240 / cfg.dt) ** 2), min_allowed=min_allowed, explain_contact_free=True, noisy_frac=0.1,
-                     bound_within_own_spread=False)
+                     bound_within_own_spread=False, noisy_cap=N_STEPS)
     lim_idx = np.flatnonzero(model.limited)
     vlim = 0.9 * (min(cfg.max_coord_velocity, 100.0) if cfg.max_coord_velocity > 0 else 100.0)
     fast = lambda st: (np.abs(st[:, 7:13]).max(1) > vlim) | (np.abs(st[:, 13 + n:13 + 2 * n]).max(1) > vlim)
